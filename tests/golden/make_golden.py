@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/.  Run in THIS container
+(needs /root/reference); the fixtures (*.npz) are committed, this script is the
+record of how they were made.  Never runs on the GPU box.
+
+Two families:
+
+ref_<script>.npz   The exact (P, q, G, h, A, b) that a reference planner script
+                   passes to ``cvxopt.solvers.qp`` at its first call, captured by
+                   executing the script's own assembly code from /root/reference
+                   with a *recording* module named ``cvxopt`` on sys.path.  The
+                   recorder performs no arithmetic: ``matrix`` keeps the NumPy
+                   array, ``solvers.qp`` stores its arguments and stops the
+                   script.  (cvxopt itself is absent from this image, see
+                   oracle/qp_oracle.py.)  Each file also stores the certified
+                   optimum (x, z, y) from oracle.qp_oracle.solve_qp and its KKT
+                   residual.
+                   Launch3DPlanner.py cannot execute on NumPy >= 1.24
+                   (ragged np.array at :33), so its QP comes from the
+                   restatement oracle/reference_qps.py::launch3d_qp instead.
+
+mpc_cfg<k>.npz     Synthetic MPC instances of BASELINE.json configs 1-3, 5 at
+                   tiny batch, with certified optimal input sequences.
+
+usage: python tests/golden/make_golden.py
+"""
+import os
+import runpy
+import sys
+import tempfile
+import types
+
+import warnings
+
+import numpy as np
+
+warnings.filterwarnings("ignore", category=DeprecationWarning)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+sys.path.insert(0, REPO)
+
+
+class _Captured(BaseException):
+    """Raised by the recorder to stop the script at its first solvers.qp call
+    (BaseException so that SE3Planner.py:198's ``except Exception`` does not
+    swallow it)."""
+
+
+def _install_recorder(store):
+    cv = types.ModuleType("cvxopt")
+
+    def matrix(x=None, size=None, tc="d"):
+        if isinstance(x, list) and len(x) == 0:
+            return np.zeros((0, 1))
+        return np.array(x, dtype=float)
+
+    sol = types.ModuleType("cvxopt.solvers")
+    sol.options = {}
+
+    def qp(P, q, G=None, h=None, A=None, b=None, *a, **k):
+        store["args"] = [None if v is None else np.array(v, dtype=float)
+                         for v in (P, q, G, h, A, b)]
+        store["options"] = dict(sol.options)
+        raise _Captured()
+
+    sol.qp = qp
+    cv.matrix = matrix
+    cv.solvers = sol
+    cv.log = np.log
+    cv.exp = np.exp
+    sys.modules["cvxopt"] = cv
+    sys.modules["cvxopt.solvers"] = sol
+    # SE3Planner.py:2 imports idlelib.run (unused); give it an empty module so
+    # the import does not drag in tkinter on a headless box.
+    idl = types.ModuleType("idlelib"); idl.__path__ = []
+    idr = types.ModuleType("idlelib.run")
+    sys.modules["idlelib"] = idl
+    sys.modules["idlelib.run"] = idr
+
+
+def capture(script):
+    store = {}
+    _install_recorder(store)
+    os.environ["MPLBACKEND"] = "Agg"
+    sys.dont_write_bytecode = True
+    cwd = os.getcwd()
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    for m in [m for m in sys.modules if m.startswith("src")]:
+        del sys.modules[m]
+    devnull = open(os.devnull, "w")
+    old = sys.stdout
+    sys.stdout = devnull
+    try:
+        runpy.run_path(os.path.join(REF, "src", "Planner", script), run_name="__main__")
+    except _Captured:
+        pass
+    finally:
+        sys.stdout = old
+        os.chdir(cwd)
+        sys.path.remove(REF)
+    if "args" not in store:
+        raise RuntimeError(f"{script}: solvers.qp was never reached")
+    return store
+
+
+def save_ref(name, P, q, G, h, A, b, source, options=None):
+    from oracle.qp_oracle import solve_qp
+    sol = solve_qp(P, q, G, h, A, b)
+    n = q.size
+    out = dict(P=P, q=q.reshape(-1),
+               G=np.zeros((0, n)) if G is None else G, h=np.zeros(0) if h is None else h.reshape(-1),
+               A=np.zeros((0, n)) if A is None else A, b=np.zeros(0) if b is None else b.reshape(-1),
+               x=sol["x"], z=sol["z"], y=sol["y"], objective=sol["primal objective"],
+               kkt=sol["kkt"]["max"], source=np.array(source))
+    np.savez_compressed(os.path.join(HERE, f"ref_{name}.npz"), **out)
+    print(f"ref_{name}: n={n} m={out['h'].size} p={out['b'].size} status={sol['status']} "
+          f"it={sol['iterations']} kkt={sol['kkt']['max']:.2e} obj={sol['primal objective']:.12g}")
+
+
+def make_reference_fixtures():
+    from oracle import reference_qps as rq
+    for script, name in [("CollocationBasedPlanner.py", "collocation1d"),
+                         ("LaunchPlannerQPFormulation.py", "launch1d"),
+                         ("SE3Planner.py", "se3_first"),
+                         ("CollocationBasedPlanner2D.py", "collocation2d_iter0")]:
+        st = capture(script)
+        P, q, G, h, A, b = st["args"]
+        save_ref(name, P, q, G, h, A, b, f"captured from src/Planner/{script} (first solvers.qp call)")
+        # the restatement in oracle/reference_qps.py must reproduce the capture bit for bit
+        fn = getattr(rq, name + "_qp", None)
+        if fn is not None:
+            for got, want, nm in zip(fn(), (P, q, G, h, A, b), "PqGhAb"):
+                if want is None:
+                    assert got is None, nm
+                else:
+                    assert np.array_equal(np.asarray(got, float).reshape(want.shape), want), (name, nm)
+            print(f"   restatement oracle/reference_qps.py::{name}_qp == capture (bit-exact)")
+    P, q, G, h, A, b = rq.launch3d_qp()
+    save_ref("launch3d", P, q, G, h, A, b,
+             "restated from src/Planner/Launch3DPlanner.py:14-199 (script itself fails on NumPy>=1.24 at :33)")
+
+
+def make_mpc_fixtures():
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_box_qp
+    from mpc_amd.configs import make_config
+    for cfg, nb in [(1, 1), (2, 16), (3, 16)]:
+        prob = make_config(cfg, batch=nb, seed=0)
+        H, F, f0 = mo.condense(prob)
+        U = np.zeros((nb, prob["N"] * prob["nu"])); lam = np.zeros_like(U); obj = np.zeros(nb); kkt = np.zeros(nb)
+        lb = np.tile(prob["u_min"], prob["N"]); ub = np.tile(prob["u_max"], prob["N"])
+        for i in range(nb):
+            q = F @ prob["x0"][i] + f0
+            s = solve_box_qp(H, q, lb, ub)
+            U[i] = s["x"]; lam[i] = s["lam"]; obj[i] = s["primal objective"]; kkt[i] = s["kkt"]["max"]
+        np.savez_compressed(os.path.join(HERE, f"mpc_cfg{cfg}.npz"),
+                            A=prob["A"], B=prob["B"], Q=prob["Q"], R=prob["R"], P=prob["P"],
+                            u_min=prob["u_min"], u_max=prob["u_max"], x0=prob["x0"],
+                            N=prob["N"], H=H, F=F, f0=f0, U=U, lam=lam, objective=obj, kkt=kkt)
+        print(f"mpc_cfg{cfg}: n={H.shape[0]} batch={nb} max kkt={kkt.max():.2e} "
+              f"active min/max={int((lam != 0).sum(1).min())}/{int((lam != 0).sum(1).max())}")
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["ref", "mpc"]
+    if "ref" in which:
+        make_reference_fixtures()
+    if "mpc" in which:
+        make_mpc_fixtures()
