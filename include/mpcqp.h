@@ -1,0 +1,128 @@
+/* mpcqp.h -- C ABI of libmpcqp.so: batched condensed-MPC QP assembly and solve on
+ * AMD MI355X (gfx950), fp64.
+ *
+ * What this boundary replaces in the reference (AOE-khkhan/MPC, src/Planner/):
+ *   - the NumPy assembly of (P, q, G, h) from the dynamics: prediction-matrix
+ *     rollout (LaunchPlannerQPFormulation.py:49-89, Launch3DPlanner.py:61-108),
+ *     Q = J'WJ, f = -J'Wc (HelperFuncs.py:6-11; LaunchPlannerQPFormulation.py:151-162),
+ *     box rows (LaunchPlannerQPFormulation.py:94-107);
+ *   - cvxopt.matrix(..., tc='d') + cvxopt.solvers.qp(P, q, G, h[, A, b])
+ *     (call sites CollocationBasedPlanner.py:59, LaunchPlannerQPFormulation.py:173,
+ *     Launch3DPlanner.py:201, CollocationBasedPlanner2D.py:359, SE3Planner.py:181,183);
+ *   - the read-back of soln['x'] (LaunchPlannerQPFormulation.py:174).
+ *
+ * Conventions
+ *   - every function returns int: 0 = MPCQP_OK, otherwise an MPCQP_E* code; no C++
+ *     exception crosses this boundary; mpcqp_last_error(h) gives the text.
+ *   - all matrix/vector arguments are DEVICE pointers to fp64, row-major, owned by
+ *     the caller (PyTorch); the handle owns only its workspace.
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream).  All calls
+ *     are asynchronous w.r.t. the host except create/destroy and workspace growth
+ *     on the first solve with a larger batch.
+ *   - a handle is not thread-safe; distinct handles are independent.
+ *
+ * Problem solved per instance b (N-step horizon, nx states, nu inputs):
+ *   minimise  sum_{k=1}^{N-1} 1/2 (x_k-xr_k)'Q(x_k-xr_k) + 1/2 (x_N-xr_N)'P(x_N-xr_N)
+ *           + sum_{k=0}^{N-1} 1/2 (u_k-ur_k)'R(u_k-ur_k)
+ *   s.t.      x_{k+1} = A_k x_k + B_k u_k,   x_0 given,   u_min <= u_k <= u_max
+ * condensed to   min 1/2 U'HU + (F x0 + f0)'U,  lb <= U <= ub,  U = [u_0;...;u_{N-1}].
+ */
+#ifndef MPCQP_H
+#define MPCQP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mpcqp_handle_s* mpcqp_handle;
+
+enum {
+    MPCQP_OK = 0,
+    MPCQP_EINVAL = 1,     /* bad shape / rank / null pointer          -> ValueError       */
+    MPCQP_ENUMERIC = 2,   /* factorisation failed (H not PD)          -> ArithmeticError  */
+    MPCQP_EHIP = 3,       /* HIP runtime error                        -> RuntimeError     */
+    MPCQP_ESTATE = 4,     /* call order (solve before factor ...)     -> RuntimeError     */
+    MPCQP_ENOTIMPL = 5    /* size outside what this build instantiates -> NotImplementedError */
+};
+
+/* per-instance status written to info.status */
+enum {
+    MPCQP_SOLVED = 0,            /* polished, KKT verified on device              */
+    MPCQP_SOLVED_INACCURATE = 1, /* ADMM met eps but polish was off / gave up      */
+    MPCQP_MAX_ITER = 2           /* ADMM hit max_iter without meeting eps (no polish) */
+};
+
+typedef struct mpcqp_dims {
+    int nx;            /* states  */
+    int nu;            /* inputs  */
+    int N;             /* horizon */
+    int n_models;      /* 1 = one model shared by the whole batch (LTI/LTV), B = one per instance */
+    int time_varying;  /* 0: A,B are (n_models, nx, nx|nu); 1: (n_models, N, nx, nx|nu)          */
+} mpcqp_dims;
+
+typedef struct mpcqp_factor_opts {
+    double rho;        /* ADMM penalty in Jacobi-scaled variables; <= 0: pick from the spectrum */
+} mpcqp_factor_opts;
+
+typedef struct mpcqp_solve_opts {
+    int    max_iter;      /* ADMM iteration cap                                   (default 25)  */
+    int    min_iter;      /* iterations before the first convergence check        (default 10)  */
+    int    check_every;   /* residual / active-set check period                   (default 5)   */
+    double eps_abs;       /* OSQP-style absolute tolerance on scaled residuals    (default 1e-6)*/
+    double eps_rel;       /* relative tolerance                                   (default 1e-6)*/
+    double alpha;         /* over-relaxation in (0,2)                             (default 1.6) */
+    int    polish;        /* 1: active-set KKT solve after ADMM (exact minimiser) (default 1)   */
+    int    polish_refine; /* iterative-refinement steps with H itself             (default 1)   */
+    int    polish_max_steps; /* cap on add/drop steps per instance               (default 4n)  */
+    int    warm_start;    /* 1: start from the (z, w) kept in the handle          (default 0)   */
+} mpcqp_solve_opts;
+
+/* all members are device pointers of length batch, each may be NULL */
+typedef struct mpcqp_info {
+    int*    iters;        /* ADMM iterations executed                                */
+    int*    status;       /* MPCQP_SOLVED ...                                        */
+    double* obj;          /* 1/2 U'HU + q'U  (same constant-free objective cvxopt
+                             reports as 'primal objective')                          */
+    double* prim_res;     /* ||x - z||_inf of the last ADMM iterate (scaled)         */
+    double* dual_res;     /* rho ||z - z_prev||_inf of the last ADMM iterate (scaled) */
+    int*    polish_steps; /* constraints added + dropped by the polish              */
+    double* lam;          /* (batch, N*nu) signed multipliers: >0 upper, <0 lower; NULL to skip */
+} mpcqp_info;
+
+/* -- lifetime ------------------------------------------------------------------ */
+int  mpcqp_create(mpcqp_handle* h, const mpcqp_dims* dims, int device_id);
+int  mpcqp_destroy(mpcqp_handle h);
+const char* mpcqp_last_error(mpcqp_handle h);   /* h may be NULL: last create error */
+void mpcqp_default_solve_opts(mpcqp_solve_opts* o);
+
+/* -- problem data (pointers are remembered, read by mpcqp_assemble) ---------------- */
+/* A: (n_models, [N,] nx, nx), B: (n_models, [N,] nx, nu), contiguous. */
+int mpcqp_set_model(mpcqp_handle h, const double* A, const double* B);
+/* Q (nx,nx), R (nu,nu), P (nx,nx) terminal; x_ref (N,nx) for x_1..x_N or NULL; u_ref (N,nu) or NULL.
+ * Shared by all models. */
+int mpcqp_set_cost(mpcqp_handle h, const double* Q, const double* R, const double* P,
+                   const double* x_ref, const double* u_ref);
+/* u_min, u_max: (nu) applied at every stage (per_stage = 0) or (N, nu) (per_stage = 1). */
+int mpcqp_set_constraints(mpcqp_handle h, const double* u_min, const double* u_max, int per_stage);
+
+/* -- kernels ----------------------------------------------------------------------- */
+/* rollout Gamma/Phi, H = Gamma'Qbar Gamma + Rbar, F = Gamma'Qbar Phi, f0  (fp64 MFMA) */
+int mpcqp_assemble(mpcqp_handle h, void* stream);
+/* Jacobi scaling, Cholesky of Hs + rho I and of Hs, explicit inverses, MFMA fragment images */
+int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream);
+/* x0 (batch, nx) -> U (batch, N*nu).  ADMM (+ polish). */
+int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U,
+                const mpcqp_info* info, const mpcqp_solve_opts* opts, void* stream);
+/* receding horizon: shift the kept (z, w) one stage forward, repeating the last stage */
+int mpcqp_shift(mpcqp_handle h, void* stream);
+
+/* -- introspection (device -> caller's device buffers; for tests and parity reports) --- */
+/* which: 0 H (n,n)  1 F (n,nx)  2 f0 (n)  3 Gamma (N nx, n)  4 Phi (N nx, nx)
+ *        5 Hs (n,n) 6 M=(Hs+rho I)^-1 (n,n)  7 Hi=Hs^-1 (n,n)  8 d (n)  9 rho (1)
+ *        10 z (batch,n) scaled  11 w (batch,n) scaled                                    */
+int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPCQP_H */

@@ -1,0 +1,226 @@
+// extern "C" surface of libmpcqp.so (declared in include/mpcqp.h).
+#include "common.h"
+#include <cstring>
+#include <new>
+
+namespace {
+
+std::string g_create_err;
+
+template <typename T>
+int dev_alloc(mpcqp_handle h, T** p, size_t count) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    HIPCHK(h, hipMemset(*p, 0, count * sizeof(T)));
+    return MPCQP_OK;
+}
+
+#define TRY(x) do { int rc_ = (x); if (rc_ != MPCQP_OK) return rc_; } while (0)
+
+int ensure_batch(mpcqp_handle h, int B) {
+    const int need = ceil_div(B, 64) * 64;
+    if (need <= h->Bcap) return MPCQP_OK;
+    TRY(dev_alloc(h, &h->z, (size_t)need * h->NP));
+    TRY(dev_alloc(h, &h->w, (size_t)need * h->NP));
+    TRY(dev_alloc(h, &h->it_ws, (size_t)need * 3));
+    TRY(dev_alloc(h, &h->rp_ws, (size_t)need));
+    TRY(dev_alloc(h, &h->rd_ws, (size_t)need));
+    h->Bcap = need;
+    h->has_state = false;
+    return MPCQP_OK;
+}
+
+__global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int nu) {
+    // one thread per (block of 16 instances, column); walk the rows forward by one stage
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nblk * 16) return;
+    const int blk = idx >> 4, c = idx & 15;
+    double* zb = z + (size_t)blk * NP * 16 + c;
+    double* wb = w + (size_t)blk * NP * 16 + c;
+    for (int r = 0; r + nu < n; ++r) {
+        zb[(size_t)r * 16] = zb[(size_t)(r + nu) * 16];
+        wb[(size_t)r * 16] = wb[(size_t)(r + nu) * 16];
+    }
+    // last stage repeats itself (z and w keep their old last-stage values)
+}
+
+__global__ void unblock_kernel(const double* zb, double* out, int B, int NP, int n) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)B * n) return;
+    const int inst = (int)(idx / n), j = (int)(idx % n);
+    out[idx] = zb[((size_t)(inst >> 4) * NP + j) * 16 + (inst & 15)];
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* mpcqp_last_error(mpcqp_handle h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+void mpcqp_default_solve_opts(mpcqp_solve_opts* o) {
+    if (!o) return;
+    o->max_iter = 25; o->min_iter = 10; o->check_every = 5;
+    o->eps_abs = 1e-6; o->eps_rel = 1e-6; o->alpha = 1.6;
+    o->polish = 1; o->polish_refine = 1; o->polish_max_steps = 0; o->warm_start = 0;
+}
+
+int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
+    if (!out || !dims) { g_create_err = "null argument"; return MPCQP_EINVAL; }
+    *out = nullptr;
+    if (dims->nx < 1 || dims->nu < 1 || dims->N < 1 || dims->n_models < 1) {
+        g_create_err = "nx, nu, N, n_models must be >= 1"; return MPCQP_EINVAL;
+    }
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) { g_create_err = "no HIP device"; return MPCQP_EHIP; }
+    if (device_id < 0 || device_id >= ndev) { g_create_err = "device_id out of range"; return MPCQP_EINVAL; }
+    mpcqp_handle h = new (std::nothrow) mpcqp_handle_s;
+    if (!h) { g_create_err = "out of host memory"; return MPCQP_EHIP; }
+    h->dev = device_id; h->dims = *dims;
+    h->n = dims->N * dims->nu; h->p = dims->N * dims->nx;
+    h->NT = ceil_div(h->n, 16); h->NP = 16 * h->NT; h->S = ceil_div(h->n, 4); h->SX = ceil_div(dims->nx + 1, 4);
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess) { g_create_err = hipGetErrorString(e); delete h; return MPCQP_EHIP; }
+    const size_t nm = dims->n_models, n = h->n, p = h->p, nx = dims->nx;
+    int rc = MPCQP_OK;
+    auto A_ = [&](auto** ptr, size_t cnt) { if (rc == MPCQP_OK) rc = dev_alloc(h, ptr, cnt); };
+    A_(&h->Gam, nm * p * n); A_(&h->QG, nm * p * n); A_(&h->Phi, nm * p * nx);
+    A_(&h->H, nm * n * n); A_(&h->F, nm * n * nx); A_(&h->f0, nm * n);
+    A_(&h->d, n); A_(&h->Hs, n * n); A_(&h->M, n * n); A_(&h->Hi, n * n); A_(&h->W1, n * n);
+    A_(&h->W2, n * std::max(n, nx + 1));
+    A_(&h->Fs1, n * (nx + 1)); A_(&h->Ku1, n * (nx + 1));
+    A_(&h->Mfrag, (size_t)h->NT * h->S * 64); A_(&h->Kbfrag, (size_t)h->NT * h->SX * 64);
+    A_(&h->Kufrag, (size_t)h->NT * h->SX * 64);
+    A_(&h->lbs, h->NP); A_(&h->ubs, h->NP); A_(&h->rho_dev, 4); A_(&h->flag_dev, 4);
+    if (rc != MPCQP_OK) { g_create_err = h->err; mpcqp_destroy(h); return rc; }
+    *out = h;
+    return MPCQP_OK;
+}
+
+int mpcqp_destroy(mpcqp_handle h) {
+    if (!h) return MPCQP_OK;
+    (void)hipSetDevice(h->dev);
+    void* ptrs[] = {h->Gam, h->QG, h->Phi, h->H, h->F, h->f0, h->d, h->Hs, h->M, h->Hi, h->W1, h->W2, h->Fs1,
+                    h->Ku1, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev,
+                    h->z, h->w, h->it_ws, h->rp_ws, h->rd_ws};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    delete h;
+    return MPCQP_OK;
+}
+
+int mpcqp_set_model(mpcqp_handle h, const double* A, const double* B) {
+    if (!h) return MPCQP_EINVAL;
+    if (!A || !B) { h->err = "set_model: null pointer"; return MPCQP_EINVAL; }
+    h->A = A; h->B = B; h->assembled = h->factored = false;
+    return MPCQP_OK;
+}
+
+int mpcqp_set_cost(mpcqp_handle h, const double* Q, const double* R, const double* P,
+                   const double* x_ref, const double* u_ref) {
+    if (!h) return MPCQP_EINVAL;
+    if (!Q || !R || !P) { h->err = "set_cost: Q, R, P are required"; return MPCQP_EINVAL; }
+    h->Q = Q; h->R = R; h->P = P; h->xref = x_ref; h->uref = u_ref;
+    h->assembled = h->factored = false;
+    return MPCQP_OK;
+}
+
+int mpcqp_set_constraints(mpcqp_handle h, const double* u_min, const double* u_max, int per_stage) {
+    if (!h) return MPCQP_EINVAL;
+    if (!u_min || !u_max) { h->err = "set_constraints: u_min and u_max are required"; return MPCQP_EINVAL; }
+    h->umin = u_min; h->umax = u_max; h->per_stage = per_stage ? 1 : 0;
+    h->factored = false;
+    return MPCQP_OK;
+}
+
+int mpcqp_assemble(mpcqp_handle h, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (!h->A || !h->Q) { h->err = "assemble: set_model and set_cost first"; return MPCQP_ESTATE; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    TRY(launch_assemble(h, static_cast<hipStream_t>(stream)));
+    h->assembled = true; h->factored = false;
+    return MPCQP_OK;
+}
+
+int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (!h->assembled) { h->err = "factor: assemble first"; return MPCQP_ESTATE; }
+    if (!h->umin) { h->err = "factor: set_constraints first"; return MPCQP_ESTATE; }
+    if (h->dims.n_models != 1) { h->err = "factor: per-instance models are not implemented in this build"; return MPCQP_ENOTIMPL; }
+    if (!admm_shared_box_supported(h->NT, h->S)) { h->err = "factor: N*nu > 128 is not implemented in this build"; return MPCQP_ENOTIMPL; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TRY(launch_factor(h, opts ? opts->rho : 0.0, st));
+    // set-up call: fetch rho and the failure flag (the only host synchronisation besides create)
+    double r3[3]; int flag = 0;
+    HIPCHK(h, hipMemcpyAsync(r3, h->rho_dev, sizeof(r3), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(&flag, h->flag_dev, sizeof(int), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    if (flag) { h->err = "factor: H is not positive definite (Cholesky pivot <= 0)"; return MPCQP_ENUMERIC; }
+    h->rho = r3[0];
+    h->factored = true; h->has_state = false;
+    return MPCQP_OK;
+}
+
+int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mpcqp_info* info,
+                const mpcqp_solve_opts* opts, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (!h->factored) { h->err = "solve: factor first"; return MPCQP_ESTATE; }
+    if (!x0 || !U || batch < 1) { h->err = "solve: x0, U must be non-null and batch >= 1"; return MPCQP_EINVAL; }
+    mpcqp_solve_opts o;
+    if (opts) o = *opts; else mpcqp_default_solve_opts(&o);
+    if (!(o.alpha > 0.0 && o.alpha < 2.0) || o.max_iter < 0) { h->err = "solve: alpha must be in (0,2), max_iter >= 0"; return MPCQP_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    TRY(ensure_batch(h, batch));
+    if (o.warm_start && h->has_state && batch != h->Blast) { h->err = "solve: warm start needs the same batch as the previous solve"; return MPCQP_EINVAL; }
+    TRY(launch_admm_shared_box(h, x0, batch, o, st));
+    TRY(launch_polish_box(h, x0, batch, U, info, o, st));
+    h->has_state = true; h->Blast = batch;
+    return MPCQP_OK;
+}
+
+int mpcqp_shift(mpcqp_handle h, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (!h->has_state) { h->err = "shift: no solution state yet"; return MPCQP_ESTATE; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    const int nblk = ceil_div(h->Blast, 16);
+    hipLaunchKernelGGL(shift_kernel, dim3(ceil_div(nblk * 16, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h->z, h->w, nblk, h->NP, h->n, h->dims.nu);
+    HIPCHK(h, hipGetLastError());
+    return MPCQP_OK;
+}
+
+int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, void* stream) {
+    if (!h || !out) return MPCQP_EINVAL;
+    const size_t n = h->n, p = h->p, nx = h->dims.nx;
+    if (model < 0 || model >= h->dims.n_models) { h->err = "get: model index out of range"; return MPCQP_EINVAL; }
+    const double* src = nullptr; size_t len = 0;
+    switch (which) {
+        case 0: src = h->H + model * n * n; len = n * n; break;
+        case 1: src = h->F + model * n * nx; len = n * nx; break;
+        case 2: src = h->f0 + model * n; len = n; break;
+        case 3: src = h->Gam + model * p * n; len = p * n; break;
+        case 4: src = h->Phi + model * p * nx; len = p * nx; break;
+        case 5: src = h->Hs; len = n * n; break;
+        case 6: src = h->M; len = n * n; break;
+        case 7: src = h->Hi; len = n * n; break;
+        case 8: src = h->d; len = n; break;
+        case 9: src = h->rho_dev; len = 3; break;
+        case 10: case 11: {
+            if (!h->has_state) { h->err = "get: no solution state yet"; return MPCQP_ESTATE; }
+            len = (size_t)h->Blast * n;
+            if ((size_t)out_len < len) { h->err = "get: output buffer too small"; return MPCQP_EINVAL; }
+            HIPCHK(h, hipSetDevice(h->dev));
+            hipLaunchKernelGGL(unblock_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0,
+                               static_cast<hipStream_t>(stream), which == 10 ? h->z : h->w, out, h->Blast, h->NP, h->n);
+            HIPCHK(h, hipGetLastError());
+            return MPCQP_OK;
+        }
+        default: h->err = "get: unknown selector"; return MPCQP_EINVAL;
+    }
+    if ((size_t)out_len < len) { h->err = "get: output buffer too small"; return MPCQP_EINVAL; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipMemcpyAsync(out, src, len * sizeof(double), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    return MPCQP_OK;
+}
+
+}  // extern "C"

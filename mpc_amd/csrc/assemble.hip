@@ -1,0 +1,172 @@
+// Condensed-QP assembly: horizon rollout of (A_k, B_k) into the prediction matrices Gamma / Phi,
+// then H = Gamma' Qbar Gamma + Rbar, F = Gamma' Qbar Phi and the constant gradient part f0.
+//
+// Reference counterparts (NumPy, one problem at a time):
+//   rollout        LaunchPlannerQPFormulation.py:49-89 (vi/xi stencil + prefix sums),
+//                  Launch3DPlanner.py:61-108
+//   H, gradient    HelperFuncs.py:6-11 getQuadProgCostFunction (Q = J'WJ, f = -J'Wc) with
+//                  J = [Gamma; I], W = blkdiag(Qbar, Rbar); LaunchPlannerQPFormulation.py:151-162
+//
+// One 256-thread workgroup per model.  Phase 1 walks the horizon: row block k of Gamma is
+// A_k times row block k-1 with B_k dropped on the block diagonal (the state-space form of the
+// reference's prefix sums); Qbar Gamma is formed on the fly.  Phase 2 is the SYRK-shaped
+// contraction Gamma'(Qbar Gamma) on v_mfma_f64_16x16x4_f64, lower tiles only and mirrored, with
+// the all-zero leading k-steps of the block-lower-triangular Gamma skipped.
+#include "common.h"
+
+namespace {
+
+struct AsmParams {
+    const double *A, *B, *Q, *R, *P, *xref, *uref;
+    double *Gam, *QG, *Phi, *H, *F, *f0;
+    int nx, nu, N, n, p, tv;
+};
+
+__global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int nx = a.nx, nu = a.nu, N = a.N, n = a.n, p = a.p;
+    const int m = blockIdx.x;                       // model index
+    const size_t strideA = (size_t)(a.tv ? N : 1) * nx * nx, strideB = (size_t)(a.tv ? N : 1) * nx * nu;
+    const double* Am = a.A + m * strideA;
+    const double* Bm = a.B + m * strideB;
+    double* Gam = a.Gam + (size_t)m * p * n;
+    double* QG = a.QG + (size_t)m * p * n;
+    double* Phi = a.Phi + (size_t)m * p * nx;
+    double* H = a.H + (size_t)m * n * n;
+    double* F = a.F + (size_t)m * n * nx;
+    double* f0 = a.f0 + (size_t)m * n;
+
+    double* rowG = reinterpret_cast<double*>(smem);     // 2 x (nx, n) ping-pong
+    double* rowP = rowG + 2 * nx * n;                   // 2 x (nx, nx)
+    const int tid = threadIdx.x;
+
+    // ---- phase 1: rollout --------------------------------------------------------------
+    for (int i = tid; i < nx * n; i += 256) rowG[i] = 0.0;
+    for (int i = tid; i < nx * nx; i += 256) rowP[i] = (i / nx == i % nx) ? 1.0 : 0.0;
+    __syncthreads();
+    for (int k = 0; k < N; ++k) {
+        const double* Ak = Am + (a.tv ? (size_t)k * nx * nx : 0);
+        const double* Bk = Bm + (a.tv ? (size_t)k * nx * nu : 0);
+        const double* Qk = (k == N - 1) ? a.P : a.Q;
+        const double* gin = rowG + (k & 1) * nx * n;
+        double* gout = rowG + ((k + 1) & 1) * nx * n;
+        const double* pin = rowP + (k & 1) * nx * nx;
+        double* pout = rowP + ((k + 1) & 1) * nx * nx;
+        for (int i = tid; i < nx * n; i += 256) {
+            const int r = i / n, c = i % n;
+            double s = 0.0;
+            const int stage = c / nu;
+            if (stage < k) {
+                for (int j = 0; j < nx; ++j) s += Ak[r * nx + j] * gin[j * n + c];
+            } else if (stage == k) {
+                s = Bk[r * nu + (c - k * nu)];
+            }
+            gout[i] = s;
+            Gam[(size_t)(k * nx + r) * n + c] = s;
+        }
+        for (int i = tid; i < nx * nx; i += 256) {
+            const int r = i / nx, c = i % nx;
+            double s = 0.0;
+            for (int j = 0; j < nx; ++j) s += Ak[r * nx + j] * pin[j * nx + c];
+            pout[i] = s;
+            Phi[(size_t)(k * nx + r) * nx + c] = s;
+        }
+        __syncthreads();
+        for (int i = tid; i < nx * n; i += 256) {
+            const int r = i / n, c = i % n;
+            double s = 0.0;
+            for (int j = 0; j < nx; ++j) s += Qk[r * nx + j] * gout[j * n + c];
+            QG[(size_t)(k * nx + r) * n + c] = s;
+        }
+        __syncthreads();
+    }
+    __threadfence_block();
+    __syncthreads();
+
+    // ---- phase 2: H = Gam' QG + Rbar on fp64 MFMA, lower tiles, mirrored ----------------------
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int NT = (n + 15) / 16;
+    const int ksteps = (p + 3) / 4;
+    int tile = 0;
+    for (int ti = 0; ti < NT; ++ti)
+        for (int tj = 0; tj <= ti; ++tj, ++tile) {
+            if ((tile & 3) != wave) continue;
+            // rows of Gamma above stage(first column of the later tile) * nx are zero in that tile
+            const int first_stage = (16 * ti) / nu;
+            const int s0 = (first_stage * nx) / 4;
+            d4 acc = {0, 0, 0, 0};
+            const int ci = 16 * ti + col, cj = 16 * tj + col;
+            for (int s = s0; s < ksteps; ++s) {
+                const int r = 4 * s + kq;
+                double av = 0.0, bv = 0.0;
+                if (r < p) {
+                    if (ci < n) av = Gam[(size_t)r * n + ci];
+                    if (cj < n) bv = QG[(size_t)r * n + cj];
+                }
+                acc = mfma_f64(av, bv, acc);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int i = 16 * ti + kq + 4 * r4, j = 16 * tj + col;
+                if (i < n && j < n && j <= i) {
+                    double v = acc[r4];
+                    if (i / nu == j / nu) v += a.R[(i % nu) * nu + (j % nu)];
+                    H[(size_t)i * n + j] = v;
+                    H[(size_t)j * n + i] = v;
+                }
+            }
+        }
+
+    // ---- phase 3: F = QG' Phi (n, nx) and f0 = -QG' xr - Rbar ur --------------------------------
+    {
+        const int NXT = (nx + 15) / 16;
+        for (int t = wave; t < NT * NXT; t += 4) {
+            const int ti = t / NXT, tj = t % NXT;
+            d4 acc = {0, 0, 0, 0};
+            const int ci = 16 * ti + col, cj = 16 * tj + col;
+            for (int s = 0; s < ksteps; ++s) {
+                const int r = 4 * s + kq;
+                double av = 0.0, bv = 0.0;
+                if (r < p) {
+                    if (ci < n) av = QG[(size_t)r * n + ci];
+                    if (cj < nx) bv = Phi[(size_t)r * nx + cj];
+                }
+                acc = mfma_f64(av, bv, acc);
+            }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int i = 16 * ti + kq + 4 * r4, j = 16 * tj + col;
+                if (i < n && j < nx) F[(size_t)i * nx + j] = acc[r4];
+            }
+        }
+        for (int i = tid; i < n; i += 256) {
+            double s = 0.0;
+            if (a.xref)
+                for (int r = 0; r < p; ++r) s -= QG[(size_t)r * n + i] * a.xref[r];
+            if (a.uref) {
+                const int st = i / nu;
+                for (int j = 0; j < nu; ++j) s -= a.R[(i % nu) * nu + j] * a.uref[st * nu + j];
+            }
+            f0[i] = s;
+        }
+    }
+}
+
+}  // namespace
+
+int launch_assemble(mpcqp_handle h, hipStream_t st) {
+    AsmParams a;
+    a.A = h->A; a.B = h->B; a.Q = h->Q; a.R = h->R; a.P = h->P; a.xref = h->xref; a.uref = h->uref;
+    a.Gam = h->Gam; a.QG = h->QG; a.Phi = h->Phi; a.H = h->H; a.F = h->F; a.f0 = h->f0;
+    a.nx = h->dims.nx; a.nu = h->dims.nu; a.N = h->dims.N; a.n = h->n; a.p = h->p; a.tv = h->dims.time_varying;
+    const size_t lds = (size_t)(2 * a.nx * a.n + 2 * a.nx * a.nx) * sizeof(double);
+    if (lds > 160 * 1024) { h->err = "assemble: nx*N*nu too large for the LDS row buffers"; return MPCQP_ENOTIMPL; }
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return MPCQP_EHIP; }
+    hipLaunchKernelGGL(assemble_kernel, dim3(h->dims.n_models), dim3(256), lds, st, a);
+    e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("assemble launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
+    return MPCQP_OK;
+}

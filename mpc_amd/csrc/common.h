@@ -1,0 +1,68 @@
+// Internal definitions shared by the libmpcqp translation units (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <string>
+#include <cstdio>
+#include "../../include/mpcqp.h"
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f64_16x16x4_f64: D(16x16) = A(16x4) B(4x16) + C.
+//   lane l holds A[l&15][l>>4], B[l>>4][l&15]; D reg r of lane l = D[(l>>4) + 4r][l&15].
+// Consequence used throughout: the D registers of row tile t, reg r ARE the B operand of
+// k-step 4t+r of a following product over the same 16 columns -- no lane movement.
+__device__ __forceinline__ d4 mfma_f64(double a, double b, d4 c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+struct mpcqp_handle_s {
+    int dev = 0;
+    mpcqp_dims dims{};
+    int n = 0, p = 0;        // decision size N*nu, stacked state size N*nx
+    int NT = 0, NP = 0;      // row tiles of 16, padded rows
+    int S = 0;               // k-steps of 4 over the n columns
+    int SX = 0;              // k-steps over [x0; 1]
+    // caller-owned problem data
+    const double *A = nullptr, *B = nullptr, *Q = nullptr, *R = nullptr, *P = nullptr;
+    const double *xref = nullptr, *uref = nullptr, *umin = nullptr, *umax = nullptr;
+    int per_stage = 0;
+    // per-model workspace (n_models copies)
+    double *Gam = nullptr, *QG = nullptr, *Phi = nullptr;   // (p,n) (p,n) (p,nx)
+    double *H = nullptr, *F = nullptr, *f0 = nullptr;       // (n,n) (n,nx) (n)
+    // shared-model solver data (model 0)
+    double *d = nullptr, *Hs = nullptr, *M = nullptr, *Hi = nullptr, *W1 = nullptr, *W2 = nullptr;
+    double *Fs1 = nullptr;      // (n, nx+1): [Fs | f0s]   qs = Fs1 [x0;1]
+    double *Ku1 = nullptr;      // (n, nx+1): [Ku | ku]    x_unc = Ku1 [x0;1]
+    double *Mfrag = nullptr, *Kbfrag = nullptr, *Kufrag = nullptr;
+    double *lbs = nullptr, *ubs = nullptr;                  // (NP) scaled bounds, padded rows = 0
+    double *rho_dev = nullptr;  // [0] rho, [1] lambda_max est, [2] lambda_min est
+    int *flag_dev = nullptr;    // [0] != 0: factorisation failed
+    double rho = 0.0;
+    // per-batch workspace (grow only)
+    int Bcap = 0;               // capacity in instances (multiple of 64)
+    int Blast = 0;              // batch of the last solve (for shift / warm start)
+    double *z = nullptr, *w = nullptr;     // blocked [Bcap/16][NP][16]
+    int *it_ws = nullptr; double *rp_ws = nullptr, *rd_ws = nullptr;
+    bool assembled = false, factored = false, has_state = false;
+    std::string err;
+};
+
+#define HIPCHK(h, call)                                                              \
+    do {                                                                             \
+        hipError_t e_ = (call);                                                      \
+        if (e_ != hipSuccess) {                                                      \
+            (h)->err = std::string(#call) + ": " + hipGetErrorString(e_);            \
+            return MPCQP_EHIP;                                                       \
+        }                                                                            \
+    } while (0)
+
+// ---- launchers implemented in the kernel translation units ----------------------
+int launch_assemble(mpcqp_handle h, hipStream_t st);
+int launch_factor(mpcqp_handle h, double rho, hipStream_t st);
+int launch_admm_shared_box(mpcqp_handle h, const double* x0, int B, const mpcqp_solve_opts& o, hipStream_t st);
+int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
+                      const mpcqp_solve_opts& o, hipStream_t st);
+int launch_shift(mpcqp_handle h, hipStream_t st);
+bool admm_shared_box_supported(int NT, int S);

@@ -1,0 +1,169 @@
+// Set-up for the shared-Hessian box-QP solver: Jacobi scaling, the "cached dense Cholesky of
+// (H + rho I)" the north star names, turned into explicit inverses so that the per-iteration
+// triangular solves become one MFMA GEMM for the whole batch, and the MFMA fragment images.
+//
+// Reference counterpart: none as code -- cvxopt factors its KKT matrix inside every call of
+// solvers.qp (LaunchPlannerQPFormulation.py:173); here the factorisation is done once per model.
+//
+// One 256-thread workgroup; this runs once per model, so clarity beats speed:
+//   d = diag(H)^-1/2, Hs = d H d,  Hi = Hs^-1,  rho (given or 0.1 sqrt(lmax lmin) from norm bounds),
+//   M = (Hs + rho I)^-1,  Fs1 = [d F | d f0],  Ku1 = -Hi Fs1,  Kb1 = -M Fs1,  lbs = lb/d, ubs = ub/d.
+#include "common.h"
+
+namespace {
+
+struct FacParams {
+    const double *H, *F, *f0, *umin, *umax;
+    double *d, *Hs, *M, *Hi, *W1, *W2, *Fs1, *Ku1, *Mfrag, *Kbfrag, *Kufrag, *lbs, *ubs, *rho_dev;
+    int* flag;
+    int n, nx, nu, NT, S, SX, per_stage;
+    double rho_in;
+};
+
+// in-place lower Cholesky of the n x n row-major W (upper part ignored); flag[0] |= 1 on failure
+__device__ void chol_inplace(double* W, int n, int* flag) {
+    const int tid = threadIdx.x;
+    for (int j = 0; j < n; ++j) {
+        if (tid == 0) {
+            const double dj = W[(size_t)j * n + j];
+            if (!(dj > 0.0)) { flag[0] |= 1; W[(size_t)j * n + j] = 1.0; }
+            else W[(size_t)j * n + j] = sqrt(dj);
+        }
+        __syncthreads();
+        const double inv = 1.0 / W[(size_t)j * n + j];
+        for (int i = j + 1 + tid; i < n; i += 256) W[(size_t)i * n + j] *= inv;
+        __syncthreads();
+        const int rem = n - j - 1;
+        for (int idx = tid; idx < rem * rem; idx += 256) {
+            const int i = j + 1 + idx / rem, k = j + 1 + idx % rem;
+            if (k <= i) W[(size_t)i * n + k] -= W[(size_t)i * n + j] * W[(size_t)k * n + j];
+        }
+        __syncthreads();
+    }
+}
+
+// X (n x n, symmetric) = (L L')^-1 given lower L in W; T is scratch for L^-1
+__device__ void inverse_from_chol(const double* W, double* T, double* X, int n) {
+    const int tid = threadIdx.x;
+    for (int i = 0; i < n; ++i) {           // row i of L^-1 from rows < i
+        const double inv = 1.0 / W[(size_t)i * n + i];
+        for (int c = tid; c <= i; c += 256) {
+            double s = (c == i) ? 1.0 : 0.0;
+            for (int k = c; k < i; ++k) s -= W[(size_t)i * n + k] * T[(size_t)k * n + c];
+            T[(size_t)i * n + c] = s * inv;
+        }
+        __syncthreads();
+    }
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx % n;
+        if (j > i) continue;
+        double s = 0.0;
+        for (int k = i; k < n; ++k) s += T[(size_t)k * n + i] * T[(size_t)k * n + j];
+        X[(size_t)i * n + j] = s;
+        X[(size_t)j * n + i] = s;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void factor_kernel(FacParams f) {
+    __shared__ double red[256];
+    const int n = f.n, nx = f.nx, nx1 = f.nx + 1, tid = threadIdx.x;
+    if (tid == 0) f.flag[0] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const double hii = f.H[(size_t)i * n + i];
+        if (!(hii > 0.0)) { f.flag[0] |= 1; f.d[i] = 1.0; }
+        else f.d[i] = 1.0 / sqrt(hii);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx % n;
+        // symmetrise so that rounding in the assembly cannot leave Hs unsymmetric
+        const double v = 0.5 * (f.H[idx] + f.H[(size_t)j * n + i]) * f.d[i] * f.d[j];
+        f.Hs[idx] = v;
+        f.W1[idx] = v;
+    }
+    __syncthreads();
+    chol_inplace(f.W1, n, f.flag);
+    inverse_from_chol(f.W1, f.W2, f.Hi, n);
+
+    // spectrum bounds: lmax <= ||Hs||_inf, lmin >= 1/||Hi||_inf
+    double a = 0.0, b = 0.0;
+    for (int i = tid; i < n; i += 256) {
+        double sa = 0.0, sb = 0.0;
+        for (int j = 0; j < n; ++j) { sa += fabs(f.Hs[(size_t)i * n + j]); sb += fabs(f.Hi[(size_t)i * n + j]); }
+        a = fmax(a, sa); b = fmax(b, sb);
+    }
+    red[tid] = a; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
+    const double lmax = red[0]; __syncthreads();
+    red[tid] = b; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
+    const double lmin = 1.0 / red[0]; __syncthreads();
+    const double rho = f.rho_in > 0.0 ? f.rho_in : 0.1 * sqrt(lmax * lmin);
+    if (tid == 0) { f.rho_dev[0] = rho; f.rho_dev[1] = lmax; f.rho_dev[2] = lmin; }
+
+    for (int idx = tid; idx < n * n; idx += 256) f.W1[idx] = f.Hs[idx] + ((idx / n == idx % n) ? rho : 0.0);
+    __syncthreads();
+    chol_inplace(f.W1, n, f.flag);
+    inverse_from_chol(f.W1, f.W2, f.M, n);
+
+    // affine maps from [x0; 1]
+    for (int idx = tid; idx < n * nx1; idx += 256) {
+        const int i = idx / nx1, c = idx % nx1;
+        f.Fs1[idx] = f.d[i] * (c < nx ? f.F[(size_t)i * nx + c] : f.f0[i]);
+    }
+    __syncthreads();
+    double* Kb1 = f.W2;     // reuse scratch: (n, nx+1)
+    for (int idx = tid; idx < n * nx1; idx += 256) {
+        const int i = idx / nx1, c = idx % nx1;
+        double su = 0.0, sb = 0.0;
+        for (int k = 0; k < n; ++k) {
+            const double fv = f.Fs1[(size_t)k * nx1 + c];
+            su -= f.Hi[(size_t)i * n + k] * fv;
+            sb -= f.M[(size_t)i * n + k] * fv;
+        }
+        f.Ku1[idx] = su;
+        Kb1[idx] = sb;
+    }
+    const int NP = 16 * f.NT;
+    for (int i = tid; i < NP; i += 256) {
+        double lo = 0.0, hi = 0.0;
+        if (i < n) {
+            const int j = f.per_stage ? i : (i % f.nu);
+            lo = f.umin[j] / f.d[i];
+            hi = f.umax[j] / f.d[i];
+        }
+        f.lbs[i] = lo; f.ubs[i] = hi;
+    }
+    __syncthreads();
+    // A-operand fragment images: frag (t, s), lane l  <-  X[16t + (l&15)][4s + (l>>4)]
+    for (int idx = tid; idx < f.NT * f.S * 64; idx += 256) {
+        const int l = idx & 63, ts = idx >> 6, t = ts / f.S, s = ts % f.S;
+        const int i = 16 * t + (l & 15), k = 4 * s + (l >> 4);
+        f.Mfrag[idx] = (i < n && k < n) ? rho * f.M[(size_t)i * n + k] : 0.0;
+    }
+    for (int idx = tid; idx < f.NT * f.SX * 64; idx += 256) {
+        const int l = idx & 63, ts = idx >> 6, t = ts / f.SX, s = ts % f.SX;
+        const int i = 16 * t + (l & 15), k = 4 * s + (l >> 4);
+        const bool in = (i < n && k < nx1);
+        f.Kbfrag[idx] = in ? Kb1[(size_t)i * nx1 + k] : 0.0;
+        f.Kufrag[idx] = in ? f.Ku1[(size_t)i * nx1 + k] : 0.0;
+    }
+}
+
+}  // namespace
+
+int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
+    FacParams f;
+    f.H = h->H; f.F = h->F; f.f0 = h->f0; f.umin = h->umin; f.umax = h->umax;
+    f.d = h->d; f.Hs = h->Hs; f.M = h->M; f.Hi = h->Hi; f.W1 = h->W1; f.W2 = h->W2;
+    f.Fs1 = h->Fs1; f.Ku1 = h->Ku1; f.Mfrag = h->Mfrag; f.Kbfrag = h->Kbfrag; f.Kufrag = h->Kufrag;
+    f.lbs = h->lbs; f.ubs = h->ubs; f.rho_dev = h->rho_dev; f.flag = h->flag_dev;
+    f.n = h->n; f.nx = h->dims.nx; f.nu = h->dims.nu; f.NT = h->NT; f.S = h->S; f.SX = h->SX;
+    f.per_stage = h->per_stage; f.rho_in = rho;
+    hipLaunchKernelGGL(factor_kernel, dim3(1), dim3(256), 0, st, f);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("factor launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
+    return MPCQP_OK;
+}

@@ -1,0 +1,495 @@
+// Polish / finalise: turn the ADMM iterate of every instance into the exact minimiser of its
+// box-constrained QP and write the caller-visible outputs.
+//
+// Reference counterpart: the last interior-point iterations of cvxopt.solvers.qp, i.e. what makes
+// soln['x'] (LaunchPlannerQPFormulation.py:174) accurate to the solver tolerance.  ADMM alone
+// converges too slowly for the 1e-6 / 1e-8 parity bar on condensed MPC Hessians (cond ~ 1e7), so,
+// as in OSQP, the iterate is only used to GUESS the active set; the guess is then corrected by a
+// dual active-set method (Goldfarb-Idnani) that works on the Schur complement S = Hi[A,A] of the
+// shared inverse Hi = Hs^-1:
+//     lam_A = S^-1 (x_unc[A] - bnd[A]),     x = x_unc - Hi[:,A] lam_A
+//   * warm phase: constraints of the guess whose multiplier has the wrong sign are released;
+//   * main phase: the most violated bound p is added; the step along
+//       z = sp Hi[:,p] - Hi[:,A] r,  r = sp S^-1 Hi[A,p]
+//     is cut short (and a constraint dropped) if a multiplier would change sign.
+// Finite termination for positive definite H; with a good guess it is one solve and no steps.
+// An optional refinement step uses Hs itself so that the answer does not inherit the rounding of
+// the explicit inverse.
+//
+// Mapping: one wave per instance, lane j owns rows j and j+64 (n <= 128); the packed Cholesky factor
+// of S lives in LDS (KMAX = 48 rows in the fast pass; instances that need more are redone by a
+// second launch with KMAX = 128 and one wave per workgroup).  No workgroup barriers.
+#include "common.h"
+
+namespace {
+
+struct PolParams {
+    const double *Hs, *Hi, *Fs1, *Ku1, *lbs, *ubs, *d;
+    const double* x0;
+    double *z, *w;                 // blocked [ceil(B/16)][NP][16]
+    const int* it_ws; const double *rp_ws, *rd_ws;
+    const int* cv_ws;              // [B]: 1 if ADMM met its eps criterion
+    int* need_big;                 // [B]: 1 if the fast pass overflowed KMAX
+    double* U;                     // [B][n]
+    mpcqp_info info;
+    int B, n, nx, NP;
+    int polish, refine, max_steps, pass;   // pass 0: fast, 1: big
+    double rho;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
+
+// value owned by "row" i of a 2-slot per-lane vector (rows lane, lane+64)
+__device__ __forceinline__ double row_get(double v0, double v1, int i) {
+    return i < 64 ? bcast(v0, i) : bcast(v1, i - 64);
+}
+
+template <int KMAX>
+struct WaveLds {
+    double L[KMAX * (KMAX + 1) / 2];
+    double xs[128];        // current x (scaled), indexable by row
+    double gs[128];        // scratch vector indexable by row
+    int A[KMAX];           // active rows, signed: +(row+1) upper, -(row+1) lower
+};
+
+template <int KMAX>
+__device__ __forceinline__ double& Lat(WaveLds<KMAX>& s, int i, int m) { return s.L[i * (i + 1) / 2 + m]; }
+
+// Cholesky of S = Hi[A,A] (k x k) into s.L.  Returns false on a non-positive pivot.
+template <int KMAX>
+__device__ bool chol_S(WaveLds<KMAX>& s, const double* Hi, int n, int k, int lane) {
+    bool ok = true;
+    for (int c = 0; c < k; ++c) {
+        const int ac = abs(s.A[c]) - 1;
+        double t[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = lane + 64 * q;
+            t[q] = 0.0;
+            if (i >= c && i < k) {
+                const int ai = abs(s.A[i]) - 1;
+                double v = Hi[(size_t)ai * n + ac];
+                for (int m = 0; m < c; ++m) v -= Lat(s, i, m) * Lat(s, c, m);
+                t[q] = v;
+            }
+        }
+        const double dcc = row_get(t[0], t[1], c);
+        if (!(dcc > 0.0)) { ok = false; break; }
+        const double dinv = 1.0 / sqrt(dcc);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int i = lane + 64 * q;
+            if (i >= c && i < k) Lat(s, i, c) = (i == c) ? sqrt(dcc) : t[q] * dinv;
+        }
+        wave_sync();
+    }
+    return ok;
+}
+
+// in-register forward solve L y = v (rows lane, lane+64)
+template <int KMAX>
+__device__ __forceinline__ void fwd_solve(WaveLds<KMAX>& s, int k, int lane, double& v0, double& v1) {
+    for (int c = 0; c < k; ++c) {
+        const double yc = row_get(v0, v1, c) / Lat(s, c, c);
+        if (lane == c) v0 = yc;
+        if (lane + 64 == c) v1 = yc;
+        if (lane > c && lane < k) v0 -= Lat(s, lane, c) * yc;
+        if (lane + 64 > c && lane + 64 < k) v1 -= Lat(s, lane + 64, c) * yc;
+    }
+}
+
+// in-register backward solve L' y = v
+template <int KMAX>
+__device__ __forceinline__ void bwd_solve(WaveLds<KMAX>& s, int k, int lane, double& v0, double& v1) {
+    for (int c = k - 1; c >= 0; --c) {
+        const double yc = row_get(v0, v1, c) / Lat(s, c, c);
+        if (lane == c) v0 = yc;
+        if (lane + 64 == c) v1 = yc;
+        if (lane < c) v0 -= Lat(s, c, lane) * yc;
+        if (lane + 64 < c) v1 -= Lat(s, c, lane + 64) * yc;
+    }
+}
+
+// rebuild the ordered active list from per-row side flags; returns k (may exceed KMAX: then
+// nothing beyond KMAX is stored)
+template <int KMAX>
+__device__ int build_list(WaveLds<KMAX>& s, const int (&side)[2], int lane) {
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const unsigned long long m = __ballot(side[q] != 0);
+        const int pos = k + __popcll(m & ((1ull << lane) - 1ull));
+        if (side[q] != 0 && pos < KMAX) s.A[pos] = side[q] * (lane + 64 * q + 1);
+        k += __popcll(m);
+    }
+    wave_sync();
+    return k;
+}
+
+template <int KMAX, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveLds<KMAX>& s = reinterpret_cast<WaveLds<KMAX>*>(smem)[wave];
+    const int inst = blockIdx.x * WAVES + wave;
+    if (inst >= p.B) return;
+    if (p.pass == 1 && p.need_big[inst] == 0) return;
+    const int n = p.n, nx1 = p.nx + 1;
+    const double* Hi = p.Hi;
+
+    // ---- per-row data ---------------------------------------------------------------------
+    double xu[2], qs[2], x[2], lo[2], hi[2], lam[2];
+    int side[2];
+    double* zb = p.z + ((size_t)(inst >> 4) * p.NP) * 16 + (inst & 15);
+    double* wb = p.w + ((size_t)(inst >> 4) * p.NP) * 16 + (inst & 15);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        xu[q] = qs[q] = x[q] = lo[q] = hi[q] = lam[q] = 0.0;
+        side[q] = 0;
+        if (j < n) {
+            double su = p.Ku1[(size_t)j * nx1 + p.nx], sq = p.Fs1[(size_t)j * nx1 + p.nx];
+            for (int c = 0; c < p.nx; ++c) {
+                const double xc = p.x0[(size_t)inst * p.nx + c];
+                su += p.Ku1[(size_t)j * nx1 + c] * xc;
+                sq += p.Fs1[(size_t)j * nx1 + c] * xc;
+            }
+            xu[q] = su; qs[q] = sq;
+            lo[q] = p.lbs[j]; hi[q] = p.ubs[j];
+            const double zz = zb[(size_t)j * 16], ww = wb[(size_t)j * 16];
+            x[q] = zz;
+            lam[q] = p.rho * ww;
+            side[q] = (zz >= hi[q] && ww > 0.0) ? 1 : ((zz <= lo[q] && ww < 0.0) ? -1 : 0);
+        }
+    }
+
+    int status = MPCQP_SOLVED_INACCURATE;
+    int steps = 0;
+    bool overflow = false, fail = false;
+
+    if (p.polish) {
+        // ---- warm phase: solve on the guessed set, release wrong-signed multipliers -------------
+        int k = 0;
+        for (;;) {
+            k = build_list(s, side, lane);
+            if (k > KMAX) { overflow = true; break; }
+            lam[0] = lam[1] = 0.0;
+            if (k == 0) { x[0] = xu[0]; x[1] = xu[1]; break; }
+            if (!chol_S(s, Hi, n, k, lane)) { fail = true; break; }
+            // rhs_i = xu[A_i] - bnd_i, in list order (rows lane, lane+64 of the LIST)
+            s.xs[lane] = xu[0]; s.xs[lane + 64] = xu[1];
+            wave_sync();
+            double v0 = 0.0, v1 = 0.0;
+            {
+                if (lane < k) { const int a = s.A[lane], r = abs(a) - 1; v0 = s.xs[r] - (a > 0 ? p.ubs[r] : p.lbs[r]); }
+                if (lane + 64 < k) { const int a = s.A[lane + 64], r = abs(a) - 1; v1 = s.xs[r] - (a > 0 ? p.ubs[r] : p.lbs[r]); }
+            }
+            fwd_solve(s, k, lane, v0, v1);
+            bwd_solve(s, k, lane, v0, v1);
+            // multipliers live in list order in (v0, v1); scatter to row order through LDS
+            s.gs[lane] = 0.0; s.gs[lane + 64] = 0.0;
+            wave_sync();
+            bool neg0 = false, neg1 = false;
+            if (lane < k) { const int a = s.A[lane]; s.gs[abs(a) - 1] = v0; neg0 = (a > 0 ? v0 : -v0) < 0.0; }
+            if (lane + 64 < k) { const int a = s.A[lane + 64]; s.gs[abs(a) - 1] = v1; neg1 = (a > 0 ? v1 : -v1) < 0.0; }
+            wave_sync();
+            lam[0] = s.gs[lane]; lam[1] = s.gs[lane + 64];
+            const bool anyneg = __any(neg0 || neg1);
+            if (!anyneg) {
+                // x = xu - Hi[:,A] lam_A, exact bounds on A
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = lane + 64 * q;
+                    double acc = xu[q];
+                    if (j < n)
+                        for (int a = 0; a < k; ++a) {
+                            const int r = abs(s.A[a]) - 1;
+                            acc -= Hi[(size_t)r * n + j] * s.gs[r];
+                        }
+                    x[q] = side[q] > 0 ? hi[q] : (side[q] < 0 ? lo[q] : acc);
+                }
+                break;
+            }
+            // release: row-order test on lam sign
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const bool rel = (side[q] != 0 && lam[q] * side[q] < 0.0);
+                if (rel) side[q] = 0;
+                steps += __popcll(__ballot(rel));
+            }
+            wave_sync();
+        }
+
+        // ---- main phase: add the most violated bound until none is violated ---------------------
+        int guard = 0;
+        while (!overflow && !fail) {
+            double vb[2];
+            int best_row = -1; double best = 0.0;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int j = lane + 64 * q;
+                vb[q] = -1.0;
+                if (j < n && side[q] == 0) {
+                    const double tol = 1e-12 * fmax(1.0, fmax(fabs(hi[q]), fabs(lo[q])));
+                    const double v = fmax(x[q] - hi[q], lo[q] - x[q]);
+                    if (v > tol) vb[q] = v;
+                }
+                if (vb[q] > best) { best = vb[q]; best_row = j; }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const double ob = __shfl_xor(best, off, 64);
+                const int orow = __shfl_xor(best_row, off, 64);
+                if (ob > best || (ob == best && orow >= 0 && (best_row < 0 || orow < best_row))) { best = ob; best_row = orow; }
+            }
+            if (best_row < 0) break;                       // primal feasible: optimal
+            if (++guard > p.max_steps) { fail = true; break; }
+            const int pr = best_row;                       // wave-uniform
+            const double xp = row_get(x[0], x[1], pr);
+            const double hip_ = p.ubs[pr], lop_ = p.lbs[pr];
+            const int sp = (xp > hip_) ? 1 : -1;
+            double v0viol = (sp > 0) ? xp - hip_ : lop_ - xp;
+            double accl = 0.0;                              // multiplier of p accumulated over partial steps
+            for (;;) {
+                // l = L^-1 Hi[A,p]  (list order), d2 = Hi[p,p] - l'l, r = sp L^-T l
+                double l0 = 0.0, l1 = 0.0;
+                if (lane < k) l0 = Hi[(size_t)(abs(s.A[lane]) - 1) * n + pr];
+                if (lane + 64 < k) l1 = Hi[(size_t)(abs(s.A[lane + 64]) - 1) * n + pr];
+                fwd_solve(s, k, lane, l0, l1);
+                double ss = (lane < k ? l0 * l0 : 0.0) + (lane + 64 < k ? l1 * l1 : 0.0);
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off, 64);
+                const double d2 = Hi[(size_t)pr * n + pr] - ss;
+                if (!(d2 > 0.0)) { fail = true; break; }
+                double r0 = l0, r1 = l1;
+                bwd_solve(s, k, lane, r0, r1);
+                r0 *= sp; r1 *= sp;
+                // scatter r to row order
+                s.gs[lane] = 0.0; s.gs[lane + 64] = 0.0;
+                wave_sync();
+                if (lane < k) s.gs[abs(s.A[lane]) - 1] = r0;
+                if (lane + 64 < k) s.gs[abs(s.A[lane + 64]) - 1] = r1;
+                wave_sync();
+                const double rr[2] = {s.gs[lane], s.gs[lane + 64]};
+                // step lengths
+                const double t2 = v0viol / d2;
+                double t1 = 1e300; int jb = -1;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (side[q] != 0 && side[q] * rr[q] > 0.0) {
+                        const double t = lam[q] / rr[q];
+                        if (t < t1) { t1 = t; jb = lane + 64 * q; }
+                    }
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) {
+                    const double ot = __shfl_xor(t1, off, 64);
+                    const int oj = __shfl_xor(jb, off, 64);
+                    if (ot < t1 || (ot == t1 && oj >= 0 && (jb < 0 || oj < jb))) { t1 = ot; jb = oj; }
+                }
+                const bool full = (t2 <= t1);
+                const double t = full ? t2 : t1;
+                // primal direction z_j = sp Hi[p][j] - sum_a Hi[A_a][j] r_a
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = lane + 64 * q;
+                    if (j < n) {
+                        double zj = sp * Hi[(size_t)pr * n + j];
+                        for (int a = 0; a < k; ++a) {
+                            const int r = abs(s.A[a]) - 1;
+                            zj -= Hi[(size_t)r * n + j] * s.gs[r];
+                        }
+                        if (side[q] == 0) x[q] -= t * zj;
+                        lam[q] -= t * rr[q];
+                    }
+                }
+                accl += sp * t;
+                ++steps;
+                if (full) {
+                    if (k + 1 > KMAX) { overflow = true; break; }
+                    // append row k of the factor: [l, sqrt(d2)]
+                    if (lane < k) Lat(s, k, lane) = l0;
+                    if (lane + 64 < k) Lat(s, k, lane + 64) = l1;
+                    if (lane == 0) { Lat(s, k, k) = sqrt(d2); s.A[k] = sp * (pr + 1); }
+                    ++k;
+#pragma unroll
+                    for (int q = 0; q < 2; ++q)
+                        if (lane + 64 * q == pr) { side[q] = sp; lam[q] = accl; x[q] = sp > 0 ? hi[q] : lo[q]; }
+                    wave_sync();
+                    break;
+                }
+                // partial step: release row jb and refactor
+                v0viol -= t * d2;
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    if (lane + 64 * q == jb) { side[q] = 0; lam[q] = 0.0; }
+                wave_sync();
+                k = build_list(s, side, lane);
+                if (k > 0 && !chol_S(s, Hi, n, k, lane)) { fail = true; break; }
+                if (++guard > p.max_steps) { fail = true; break; }
+            }
+        }
+
+        // ---- refinement with Hs itself --------------------------------------------------------
+        if (!overflow && !fail) {
+            for (int itr = 0; itr < p.refine; ++itr) {
+                s.xs[lane] = x[0]; s.xs[lane + 64] = x[1];
+                wave_sync();
+                double g[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = lane + 64 * q;
+                    g[q] = 0.0;
+                    if (j < n) {
+                        double acc = qs[q];
+                        for (int m = 0; m < n; ++m) acc += p.Hs[(size_t)m * n + j] * s.xs[m];
+                        if (side[q] == 0) g[q] = acc;   // stationarity residual of a free row
+                        else lam[q] = -acc;             // the multiplier this x really has
+                    }
+                }
+                s.gs[lane] = g[0]; s.gs[lane + 64] = g[1];
+                wave_sync();
+                double dx[2];
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = lane + 64 * q;
+                    dx[q] = 0.0;
+                    if (j < n) {
+                        double acc = 0.0;
+                        for (int m = 0; m < n; ++m) acc -= Hi[(size_t)m * n + j] * s.gs[m];
+                        dx[q] = acc;
+                    }
+                }
+                if (k > 0) {
+                    wave_sync();
+                    s.gs[lane] = dx[0]; s.gs[lane + 64] = dx[1];
+                    wave_sync();
+                    double v0 = 0.0, v1 = 0.0;
+                    if (lane < k) v0 = s.gs[abs(s.A[lane]) - 1];
+                    if (lane + 64 < k) v1 = s.gs[abs(s.A[lane + 64]) - 1];
+                    fwd_solve(s, k, lane, v0, v1);
+                    bwd_solve(s, k, lane, v0, v1);
+                    wave_sync();
+                    s.gs[lane] = 0.0; s.gs[lane + 64] = 0.0;
+                    wave_sync();
+                    if (lane < k) s.gs[abs(s.A[lane]) - 1] = v0;
+                    if (lane + 64 < k) s.gs[abs(s.A[lane + 64]) - 1] = v1;
+                    wave_sync();
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int j = lane + 64 * q;
+                        if (j < n) {
+                            double acc = dx[q];
+                            for (int a = 0; a < k; ++a) {
+                                const int r = abs(s.A[a]) - 1;
+                                acc -= Hi[(size_t)r * n + j] * s.gs[r];
+                            }
+                            if (side[q] == 0) x[q] += acc;
+                            else lam[q] += s.gs[j];
+                        }
+                    }
+                } else {
+                    x[0] += dx[0]; x[1] += dx[1];
+                }
+                wave_sync();
+            }
+            status = MPCQP_SOLVED;
+        }
+    }
+
+    if (overflow && p.pass == 0) {          // redo in the big pass
+        if (lane == 0) p.need_big[inst] = 1;
+        return;
+    }
+    if (p.pass == 0 && lane == 0) p.need_big[inst] = 0;
+
+    if (!p.polish || fail || overflow) {
+        // ADMM answer as is: x = z (feasible), lam = rho w
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < n) { x[q] = zb[(size_t)j * 16]; lam[q] = p.rho * wb[(size_t)j * 16]; }
+        }
+        status = p.cv_ws[inst] ? MPCQP_SOLVED_INACCURATE : MPCQP_MAX_ITER;
+    }
+
+    // ---- objective 1/2 x'Hs x + qs'x ---------------------------------------------------------------
+    double obj;
+    if (status == MPCQP_SOLVED) {
+        // stationarity Hs x + qs + lam = 0  =>  obj = 1/2 (qs - lam)'x
+        obj = 0.5 * ((qs[0] - lam[0]) * x[0] + (qs[1] - lam[1]) * x[1]);
+    } else {
+        s.xs[lane] = x[0]; s.xs[lane + 64] = x[1];
+        wave_sync();
+        obj = 0.0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int j = lane + 64 * q;
+            if (j < n) {
+                double acc = 0.0;
+                for (int m = 0; m < n; ++m) acc += p.Hs[(size_t)m * n + j] * s.xs[m];
+                obj += x[q] * (0.5 * acc + qs[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) obj += __shfl_xor(obj, off, 64);
+
+    // ---- outputs ------------------------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int j = lane + 64 * q;
+        if (j < n) {
+            const double dj = p.d[j];
+            p.U[(size_t)inst * n + j] = dj * x[q];
+            if (p.info.lam) p.info.lam[(size_t)inst * n + j] = lam[q] / dj;
+            if (status == MPCQP_SOLVED) {       // keep the polished point as warm-start state
+                zb[(size_t)j * 16] = x[q];
+                wb[(size_t)j * 16] = lam[q] / p.rho;
+            }
+        }
+    }
+    if (lane == 0) {
+        if (p.info.status) p.info.status[inst] = status;
+        if (p.info.obj) p.info.obj[inst] = obj;
+        if (p.info.iters) p.info.iters[inst] = p.it_ws[inst];
+        if (p.info.prim_res) p.info.prim_res[inst] = p.rp_ws[inst];
+        if (p.info.dual_res) p.info.dual_res[inst] = p.rd_ws[inst];
+        if (p.info.polish_steps) p.info.polish_steps[inst] = steps;
+    }
+}
+
+template <int KMAX, int WAVES>
+int launch_pol(const PolParams& p, hipStream_t st) {
+    const size_t lds = sizeof(WaveLds<KMAX>) * WAVES;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_box_kernel<KMAX, WAVES>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((polish_box_kernel<KMAX, WAVES>), dim3(ceil_div(p.B, WAVES)), dim3(64 * WAVES), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+}  // namespace
+
+int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
+                      const mpcqp_solve_opts& o, hipStream_t st) {
+    PolParams p;
+    p.Hs = h->Hs; p.Hi = h->Hi; p.Fs1 = h->Fs1; p.Ku1 = h->Ku1; p.lbs = h->lbs; p.ubs = h->ubs; p.d = h->d;
+    p.x0 = x0; p.z = h->z; p.w = h->w; p.it_ws = h->it_ws; p.rp_ws = h->rp_ws; p.rd_ws = h->rd_ws;
+    p.need_big = h->it_ws + h->Bcap;      // int workspace: [iters | need_big | converged]
+    p.cv_ws = h->it_ws + 2 * (size_t)h->Bcap;
+    p.U = U;
+    if (info) p.info = *info; else p.info = mpcqp_info{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    p.B = B; p.n = h->n; p.nx = h->dims.nx; p.NP = h->NP;
+    p.polish = o.polish; p.refine = o.polish_refine; p.max_steps = o.polish_max_steps > 0 ? o.polish_max_steps : 4 * h->n + 16;
+    p.rho = h->rho;
+    p.pass = 0;
+    int rc = launch_pol<48, 4>(p, st);
+    if (rc == 0 && o.polish) { p.pass = 1; rc = launch_pol<128, 1>(p, st); }
+    if (rc != 0) { h->err = std::string("polish launch: ") + hipGetErrorString((hipError_t)rc); return MPCQP_EHIP; }
+    return MPCQP_OK;
+}

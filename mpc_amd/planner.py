@@ -1,0 +1,237 @@
+"""Planner facade over libmpcqp.so: model / cost / constraint set-up and
+``solve(x0)`` returning the optimal input sequence for a whole batch of initial
+states.
+
+The reference has no such class -- every script under src/Planner/ is
+module-level code that builds (P, q, G, h) with NumPy and calls
+``cvxopt.solvers.qp`` once (LaunchPlannerQPFormulation.py:49-173).  The facade
+is the entry-point set BASELINE.json's north star asks for; its semantics are
+fixed in SURVEY.md section 8(b2).  What it replaces, step by step:
+
+  set_model / set_cost   constants + prediction matrices + J'WJ
+                         (LaunchPlannerQPFormulation.py:14-89, :130-162)
+  set_constraints        input box rows (LaunchPlannerQPFormulation.py:94-107)
+  solve(x0)              cvxopt.matrix + solvers.qp + soln['x'] (:165-174)
+
+PyTorch is used only for device memory and streams; all arithmetic is in the
+HIP library.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from types import SimpleNamespace
+
+import numpy as np
+import torch
+
+from . import _lib
+
+
+def _as_dev(x, device, shape=None, name="tensor"):
+    if x is None:
+        return None
+    t = torch.as_tensor(np.asarray(x) if not torch.is_tensor(x) else x)
+    t = t.to(device=device, dtype=torch.float64).contiguous()
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise ValueError(f"{name}: expected shape {tuple(shape)}, got {tuple(t.shape)}")
+    return t
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Planner:
+    """Batched linear-MPC planner:  min sum 1/2|x_k-xr_k|_Q^2 + 1/2|u_k-ur_k|_R^2 + terminal P
+    s.t. x_{k+1} = A_k x_k + B_k u_k, u_min <= u_k <= u_max, for a batch of x0."""
+
+    def __init__(self, nx, nu, N, device="cuda:0"):
+        self.nx, self.nu, self.N = int(nx), int(nu), int(N)
+        self.n = self.N * self.nu
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise RuntimeError("mpc_amd.Planner runs on a ROCm device only (no CPU path)")
+        self._lib = _lib.load()
+        self._h = None
+        self._keep = {}          # tensors whose pointers the handle remembers
+        self._time_varying = None
+        self._n_models = None
+        self._dirty = True
+        self.rho = None
+        self.info = None
+        self.opts = _lib.SolveOpts()
+        self._lib.mpcqp_default_solve_opts(C.byref(self.opts))
+
+    # ---- lifetime ------------------------------------------------------------------
+    def _create(self, n_models, time_varying):
+        if self._h is not None and (n_models, time_varying) == (self._n_models, self._time_varying):
+            return
+        self.close()
+        dims = _lib.Dims(self.nx, self.nu, self.N, n_models, int(time_varying))
+        h = C.c_void_p()
+        rc = self._lib.mpcqp_create(C.byref(h), C.byref(dims), self.device.index or 0)
+        _lib.check(self._lib, None, rc)
+        self._h, self._n_models, self._time_varying = h, n_models, time_varying
+        # re-register data given before the handle existed / for the old handle
+        if "Q" in self._keep:
+            self._push_cost()
+        if "u_min" in self._keep:
+            self._push_constraints()
+
+    def close(self):
+        if self._h is not None:
+            self._lib.mpcqp_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        _lib.check(self._lib, self._h, rc)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- problem data ----------------------------------------------------------------
+    def set_model(self, A, B):
+        """A: (nx,nx) | (N,nx,nx) | (1,N,nx,nx);  B likewise with nu columns.
+        A leading batch dimension > 1 (one model per instance) is not implemented yet."""
+        A = _as_dev(A, self.device); B = _as_dev(B, self.device)
+        nx, nu, N = self.nx, self.nu, self.N
+        if A.dim() == 2:
+            tv = False
+        elif A.dim() == 3:
+            tv = True
+        elif A.dim() == 4:
+            if A.shape[0] != 1:
+                raise NotImplementedError("per-instance models (leading batch dimension > 1) are not implemented yet")
+            A = A[0]; B = B[0] if B.dim() == 4 else B
+            tv = True
+        else:
+            raise ValueError("A must have 2, 3 or 4 dimensions")
+        A = A.reshape((N, nx, nx) if tv else (nx, nx)).contiguous()
+        B = B.reshape((N, nx, nu) if tv else (nx, nu)).contiguous()
+        self._keep["A"], self._keep["B"] = A, B
+        self._create(1, tv)
+        self._check(self._lib.mpcqp_set_model(self._h, _ptr(A), _ptr(B)))
+        self._dirty = True
+        return self
+
+    def _push_cost(self):
+        k = self._keep
+        self._check(self._lib.mpcqp_set_cost(self._h, _ptr(k["Q"]), _ptr(k["R"]), _ptr(k["P"]),
+                                             _ptr(k.get("x_ref")), _ptr(k.get("u_ref"))))
+
+    def set_cost(self, Q, R, P_terminal=None, x_ref=None, u_ref=None):
+        """Q (nx,nx), R (nu,nu), P_terminal (nx,nx, default Q); x_ref (N,nx) for x_1..x_N, u_ref (N,nu)."""
+        nx, nu, N = self.nx, self.nu, self.N
+        k = self._keep
+        k["Q"] = _as_dev(Q, self.device, (nx, nx), "Q")
+        k["R"] = _as_dev(R, self.device, (nu, nu), "R")
+        k["P"] = _as_dev(Q if P_terminal is None else P_terminal, self.device, (nx, nx), "P_terminal")
+        k["x_ref"] = _as_dev(x_ref, self.device, (N, nx), "x_ref")
+        k["u_ref"] = _as_dev(u_ref, self.device, (N, nu), "u_ref")
+        if self._h is not None:
+            self._push_cost()
+        self._dirty = True
+        return self
+
+    def _push_constraints(self):
+        k = self._keep
+        self._check(self._lib.mpcqp_set_constraints(self._h, _ptr(k["u_min"]), _ptr(k["u_max"]), k["per_stage"]))
+
+    def set_constraints(self, u_min, u_max, x_min=None, x_max=None, C=None, c_min=None, c_max=None):
+        """Input box u_min <= u_k <= u_max, (nu,) or (N,nu).  State boxes / polytopic rows are the
+        general-constraint path and are not implemented yet."""
+        if any(v is not None for v in (x_min, x_max, C, c_min, c_max)):
+            raise NotImplementedError("state-box / polytopic constraints are not implemented yet")
+        u_min = _as_dev(u_min, self.device); u_max = _as_dev(u_max, self.device)
+        if u_min.numel() == self.nu:
+            per_stage = 0
+            u_min = u_min.reshape(self.nu); u_max = u_max.reshape(self.nu)
+        elif u_min.numel() == self.n:
+            per_stage = 1
+            u_min = u_min.reshape(self.n); u_max = u_max.reshape(self.n)
+        else:
+            raise ValueError("u_min/u_max must have nu or N*nu elements")
+        if bool((u_min > u_max).any()):
+            raise ValueError("u_min > u_max")
+        self._keep.update(u_min=u_min.contiguous(), u_max=u_max.contiguous(), per_stage=per_stage)
+        if self._h is not None:
+            self._push_constraints()
+        self._dirty = True
+        return self
+
+    # ---- kernels -----------------------------------------------------------------------
+    def setup(self, rho=None):
+        """assemble (rollout, H, F, f0) + factor; called lazily by solve()."""
+        if self._h is None or "Q" not in self._keep or "u_min" not in self._keep:
+            raise RuntimeError("set_model, set_cost and set_constraints must be called before solve")
+        self._check(self._lib.mpcqp_assemble(self._h, self._stream()))
+        fo = _lib.FactorOpts(float(rho) if rho else 0.0)
+        self._check(self._lib.mpcqp_factor(self._h, C.byref(fo), self._stream()))
+        self.rho = float(self.get("rho")[0])
+        self._dirty = False
+        return self
+
+    def solve(self, x0, warm_start=None, want_multipliers=False, **opts):
+        """x0 (B,nx) -> U (B,N,nu) on the device; per-instance diagnostics in ``self.info``
+        (iters, status, obj, prim_res, dual_res, polish_steps[, lam]).
+        opts: max_iter, min_iter, check_every, eps_abs, eps_rel, alpha, polish, polish_refine,
+        polish_max_steps; rho (forces a re-factor)."""
+        rho = opts.pop("rho", None)
+        if self._dirty or (rho is not None and rho != self.rho):
+            self.setup(rho)
+        x0 = _as_dev(x0, self.device)
+        if x0.dim() == 1:
+            x0 = x0.reshape(1, -1)
+        if x0.dim() != 2 or x0.shape[1] != self.nx:
+            raise ValueError(f"x0: expected (B, {self.nx}), got {tuple(x0.shape)}")
+        B = x0.shape[0]
+        o = _lib.SolveOpts.from_buffer_copy(self.opts)
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k!r}")
+            setattr(o, k, v)
+        if warm_start is not None:
+            o.warm_start = int(bool(warm_start))
+        dev = self.device
+        U = torch.empty((B, self.N, self.nu), dtype=torch.float64, device=dev)
+        info = SimpleNamespace(
+            iters=torch.empty(B, dtype=torch.int32, device=dev),
+            status=torch.empty(B, dtype=torch.int32, device=dev),
+            obj=torch.empty(B, dtype=torch.float64, device=dev),
+            prim_res=torch.empty(B, dtype=torch.float64, device=dev),
+            dual_res=torch.empty(B, dtype=torch.float64, device=dev),
+            polish_steps=torch.empty(B, dtype=torch.int32, device=dev),
+            lam=torch.empty((B, self.n), dtype=torch.float64, device=dev) if want_multipliers else None)
+        ci = _lib.Info(*[_ptr(getattr(info, f[0])) for f in _lib.Info._fields_])
+        self._check(self._lib.mpcqp_solve(self._h, _ptr(x0), B, _ptr(U), C.byref(ci), C.byref(o), self._stream()))
+        self.info = info
+        return U
+
+    def shift(self):
+        """Receding horizon: move the kept primal/dual state one stage forward (last stage repeated)."""
+        self._check(self._lib.mpcqp_shift(self._h, self._stream()))
+        return self
+
+    # ---- introspection -------------------------------------------------------------------
+    _GET = {"H": 0, "F": 1, "f0": 2, "Gamma": 3, "Phi": 4, "Hs": 5, "M": 6, "Hi": 7, "d": 8, "rho": 9,
+            "z": 10, "w": 11}
+
+    def get(self, name, batch=None):
+        n, p, nx = self.n, self.N * self.nx, self.nx
+        shapes = {"H": (n, n), "F": (n, nx), "f0": (n,), "Gamma": (p, n), "Phi": (p, nx), "Hs": (n, n),
+                  "M": (n, n), "Hi": (n, n), "d": (n,), "rho": (3,)}
+        if name in ("z", "w"):
+            if batch is None:
+                raise ValueError("get('z'|'w') needs batch=")
+            shape = (batch, n)
+        else:
+            shape = shapes[name]
+        out = torch.empty(shape, dtype=torch.float64, device=self.device)
+        self._check(self._lib.mpcqp_get(self._h, self._GET[name], 0, _ptr(out), out.numel(), self._stream()))
+        return out
