@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MPC QP hot path on MI355X.
+
+Metric (BASELINE.json): QP solves/sec at batch 65,536, nx=12 nu=4 N=30 (quadrotor hover MPC,
+config 3), fp64, synthetic x0 (numpy default_rng(seed)), random-free model.  One "step" = one
+pass of the hot path over one batch: mpcqp_solve (ADMM kernel + polish kernel) with x0 already
+resident in HBM; the model set-up (assemble + factor) is outside the timed region because the
+model is shared and fixed (LTI) -- it is reported as `setup_ms`.
+
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 is launched by the driver as torch.distributed.run with one rank per GPU; every rank solves
+its own 65,536-instance shard (weak scaling, no data-path collective), the step ends with the
+all-reduce of the "all solved" flag the north star names; the all-gather of the solutions is timed
+separately (config.allgather_ms) because its volume grows with N and a caller only needs it when
+the host wants every trajectory.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (datasheet)
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(prob, seconds=15.0):
+    """Time the C restatement of the reference's solver class (oracle/qp_ipm.c: dense Mehrotra
+    IPM on (P,q,G,h) with cvxopt's default tolerances, one QP per thread) on a bounded sample of
+    the SAME workload, on this box's host cores.  Checker/baseline only -- never the product."""
+    from oracle import cpu_baseline as cb
+    from oracle import mpc_oracle as mo
+    H, F, f0 = mo.condense(prob)
+    lb = np.tile(prob["u_min"], prob["N"]); ub = np.tile(prob["u_max"], prob["N"])
+    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
+    cores = int(os.environ.get("OMP_NUM_THREADS", cores)) if os.environ.get("OMP_NUM_THREADS", "").isdigit() else cores
+    cores = max(1, min(cores, 16))
+    # calibrate on 64 instances single-thread, then size the sample to ~`seconds` of wall time
+    _, _, _, t1 = cb.solve_batch_box(H, F, f0, lb, ub, prob["x0"][:64], nthreads=1)
+    per_core = 64 / t1
+    nsamp = int(min(len(prob["x0"]), max(256, per_core * cores * seconds)))
+    U, it, bad, t = cb.solve_batch_box(H, F, f0, lb, ub, prob["x0"][:nsamp], nthreads=cores)
+    return {"value": nsamp / t, "unit": "solves/s", "cores": cores, "kind": "port",
+            "sample": f"first {nsamp} of the 65,536 x0 (same H,F,bounds); dense Mehrotra IPM, cvxopt default "
+                      f"tolerances, mean {float(it.mean()):.1f} iterations, {bad} not optimal; "
+                      f"single-core {per_core:.0f} solves/s",
+            "single_core": per_core}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--max-iter", type=int, default=None)
+    ap.add_argument("--rho", type=float, default=None)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    else:
+        torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    from mpc_amd.configs import make_config
+    from mpc_amd.planner import Planner
+
+    B = args.batch
+    prob = make_config(3, batch=B, seed=rank)       # every rank draws its own x0 shard
+    pl = Planner(prob["nx"], prob["nu"], prob["N"], device=dev)
+    pl.set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+    pl.set_constraints(prob["u_min"], prob["u_max"])
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    pl.setup(rho=args.rho)
+    torch.cuda.synchronize(dev)
+    setup_ms = (time.perf_counter() - t0) * 1e3
+    x0 = torch.as_tensor(prob["x0"], device=dev)
+    opts = {}
+    if args.max_iter is not None:
+        opts["max_iter"] = args.max_iter
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def step():
+        U = pl.solve(x0, **opts)
+        if dist is not None:
+            flag.copy_((pl.info.status == 0).all().to(torch.int32).reshape(1))
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return U
+
+    for _ in range(args.warmup):
+        U = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        U = step()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    info = pl.info
+    n_solved = int((info.status == 0).sum().item())
+    iters_mean = float(info.iters.float().mean().item())
+    iters_max = int(info.iters.max().item())
+    psteps_mean = float(info.polish_steps.float().mean().item())
+    psteps_max = int(info.polish_steps.max().item())
+
+    # ---- per-kernel device time with events on the stream the kernels run on (torch's current stream)
+    def timed(fn, reps):
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        fn(); torch.cuda.synchronize(dev)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize(dev)
+        return e0.elapsed_time(e1) / reps       # ms
+
+    reps = max(5, min(args.steps, 20))
+    admm_ms = timed(lambda: pl.solve(x0, stages=1, **opts), reps)
+    both_ms = timed(lambda: pl.solve(x0, **opts), reps)
+    polish_ms = max(both_ms - admm_ms, 0.0)
+
+    allgather_ms = None
+    if dist is not None:
+        gathered = torch.empty((world,) + tuple(U.shape), dtype=U.dtype, device=dev)
+        allgather_ms = timed(lambda: dist.all_gather_into_tensor(gathered, U), 5)
+
+    # ---- roofline of the dominant kernel (the ADMM kernel), SURVEY.md section 8(d) counts:
+    # flops/iteration/instance = 2 n^2 + 10 (n + m), m = n box rows, times the iterations executed
+    n = pl.n
+    flops_per_iter = 2 * n * n + 10 * (n + n)
+    admm_flops = B * iters_mean * flops_per_iter
+    achieved_tf = admm_flops / (admm_ms * 1e-3) / 1e12
+    # compulsory HBM bytes per solve: x0 in, U + info out, plus the (z, w) state the kernels exchange
+    hbm_bytes_per_solve = 8 * prob["nx"] + 8 * n + 16 + 4 * 8 * pl.n
+    hbm_gbs = B * hbm_bytes_per_solve / (both_ms * 1e-3) / 1e9
+
+    out = None
+    if rank == 0:
+        total = world * B * args.steps
+        out = {
+            "metric": "QP solves/sec (node) at batch 65,536, nx=12 nu=4 N=30",
+            "value": total / dt, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "configs[2]: quadrotor hover MPC nx=12 nu=4 N=30 (n=120 box-constrained QP), "
+                                   f"{B} random x0 per GPU, shared LTI model",
+                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world} (independent shards)",
+                       "algorithm": "ADMM (shared (Hs+rho I)^-1, fp64 MFMA) + dual active-set polish",
+                       "admm_iters_mean": iters_mean, "admm_iters_max": iters_max,
+                       "polish_steps_mean": psteps_mean, "polish_steps_max": psteps_max,
+                       "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": setup_ms,
+                       "p50_batch_latency_ms": both_ms, "admm_kernel_ms": admm_ms, "polish_kernels_ms": polish_ms,
+                       "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if world > 1 else "none",
+                       "allgather_ms": allgather_ms,
+                       "hbm_GBps_compulsory": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS},
+            "roofline": {"bound": "mfma", "kernel": "admm_shared_box_kernel<8,30>", "achieved": achieved_tf,
+                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                         "traffic": None,
+                         "flops_per_launch": admm_flops, "launch_ms": admm_ms},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
+            except Exception as e:      # the baseline is a report, never a reason to lose the GPU line
+                out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
+                                       "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -27,7 +27,7 @@ class SolveOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("min_iter", C.c_int), ("check_every", C.c_int),
                 ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("alpha", C.c_double),
                 ("polish", C.c_int), ("polish_refine", C.c_int), ("polish_max_steps", C.c_int),
-                ("warm_start", C.c_int)]
+                ("warm_start", C.c_int), ("stages", C.c_int)]
 
 
 class Info(C.Structure):

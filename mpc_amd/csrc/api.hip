@@ -61,7 +61,7 @@ void mpcqp_default_solve_opts(mpcqp_solve_opts* o) {
     if (!o) return;
     o->max_iter = 25; o->min_iter = 10; o->check_every = 5;
     o->eps_abs = 1e-6; o->eps_rel = 1e-6; o->alpha = 1.6;
-    o->polish = 1; o->polish_refine = 1; o->polish_max_steps = 0; o->warm_start = 0;
+    o->polish = 1; o->polish_refine = 1; o->polish_max_steps = 0; o->warm_start = 0; o->stages = 3;
 }
 
 int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
@@ -172,8 +172,11 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
     hipStream_t st = static_cast<hipStream_t>(stream);
     TRY(ensure_batch(h, batch));
     if (o.warm_start && h->has_state && batch != h->Blast) { h->err = "solve: warm start needs the same batch as the previous solve"; return MPCQP_EINVAL; }
-    TRY(launch_admm_shared_box(h, x0, batch, o, st));
-    TRY(launch_polish_box(h, x0, batch, U, info, o, st));
+    if ((o.stages & 2) && !(o.stages & 1) && !(h->has_state && batch == h->Blast)) {
+        h->err = "solve: stages=2 needs the state of a previous solve of the same batch"; return MPCQP_ESTATE;
+    }
+    if (o.stages & 1) TRY(launch_admm_shared_box(h, x0, batch, o, st));
+    if (o.stages & 2) TRY(launch_polish_box(h, x0, batch, U, info, o, st));
     h->has_state = true; h->Blast = batch;
     return MPCQP_OK;
 }

@@ -1,0 +1,62 @@
+"""ctypes wrapper of oracle/libqpipm.so (built from oracle/qp_ipm.c) -- TEST /
+BASELINE INFRASTRUCTURE ONLY (see oracle/qp_oracle.py header for who may
+import this)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def load():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "libqpipm.so")
+        if not os.path.exists(path):
+            raise RuntimeError(f"{path} missing: run `make -C oracle` (or __graft_entry__.build())")
+        lib = C.CDLL(path)
+        dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        lib.qp_ipm_batch_box.restype = C.c_int
+        lib.qp_ipm_batch_box.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, C.c_int,
+                                         C.c_double, C.c_double, C.c_double]
+        lib.qp_ipm_solve.restype = C.c_int
+        lib.qp_ipm_solve.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, C.c_int, C.c_double, C.c_double,
+                                     C.c_double, ip, dp]
+        lib.qp_ipm_worksize.restype = C.c_long
+        lib.qp_ipm_worksize.argtypes = [C.c_int, C.c_int]
+        _LIB = lib
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def solve_batch_box(H, F, f0, lb, ub, x0, nthreads=1, abstol=1e-7, reltol=1e-6, feastol=1e-7):
+    """Interior-point solve of every row of x0; tolerances default to cvxopt's.
+    Returns (U, iters, n_not_optimal, seconds)."""
+    lib = load()
+    H, F, f0, lb, ub, x0 = [np.ascontiguousarray(a, dtype=np.float64) for a in (H, F, f0, lb, ub, x0)]
+    n, nx = F.shape
+    B = x0.shape[0]
+    U = np.zeros((B, n)); it = np.zeros(B, dtype=np.int32)
+    t = time.perf_counter()
+    bad = lib.qp_ipm_batch_box(n, nx, B, _p(H), _p(F), _p(f0), _p(lb), _p(ub), _p(x0), _p(U),
+                               it.ctypes.data_as(C.POINTER(C.c_int)), int(nthreads), abstol, reltol, feastol)
+    return U, it, bad, time.perf_counter() - t
+
+
+def solve_dense(P, q, G, h, abstol=1e-7, reltol=1e-6, feastol=1e-7, maxiters=100):
+    lib = load()
+    P, q, G, h = [np.ascontiguousarray(a, dtype=np.float64) for a in (P, q.reshape(-1), G, h.reshape(-1))]
+    n, m = q.size, h.size
+    x = np.zeros(n); z = np.zeros(m); it = C.c_int(0)
+    work = np.zeros(lib.qp_ipm_worksize(n, m))
+    st = lib.qp_ipm_solve(n, m, _p(P), _p(q), _p(G), _p(h), _p(x), _p(z), maxiters, abstol, reltol, feastol,
+                          C.byref(it), _p(work))
+    return x, z, st, it.value
