@@ -72,7 +72,8 @@ typedef struct mpcqp_solve_opts {
     double eps_rel;       /* relative tolerance                                   (default 1e-6)*/
     double alpha;         /* over-relaxation in (0,2)                             (default 1.6) */
     int    polish;        /* 1: active-set KKT solve after ADMM (exact minimiser) (default 1)   */
-    int    polish_refine; /* iterative-refinement steps with H itself             (default 1)   */
+    int    polish_refine; /* iterative-refinement steps with H itself; -1 = one step only if
+                             max|Hs Hs^-1 - I| > 1e-9 at factor time              (default -1)  */
     int    polish_max_steps; /* cap on add/drop steps per instance               (default 4n)  */
     int    warm_start;    /* 1: start from the (z, w) kept in the handle          (default 0)   */
     int    stages;        /* bit 0: run the ADMM kernel, bit 1: run polish/finalise (default 3);

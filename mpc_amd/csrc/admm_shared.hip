@@ -23,7 +23,7 @@ struct AdmmParams {
     const double* lbs;      // [NP]
     const double* ubs;      // [NP]
     const double* x0;       // [B][nx]
-    double* z;              // blocked [ceil(B/16)][NP][16]
+    double* z;              // [Bcap][NP] row-major (Bcap is a multiple of 64: no bounds checks)
     double* w;
     int* iters;             // [B]
     int* conv;              // [B] 1 if the eps criterion was met
@@ -136,15 +136,15 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
             if (s < p.SX) acc = mfma_f64(p.Kbfrag[(size_t)(t * p.SX + s) * 64 + lane], xf[s], acc);
         b0[t] = acc;
     }
-    double* zblk = p.z + (size_t)blk * NP * 16;
-    double* wblk = p.w + (size_t)blk * NP * 16;
+    double* zrow = p.z + (size_t)inst * NP;     // instance-major: what the polish reads coalesced
+    double* wrow = p.w + (size_t)inst * NP;
     if (p.warm) {
 #pragma unroll
         for (int t = 0; t < NT; ++t)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
-                const double zz = zblk[row * 16 + col], ww = wblk[row * 16 + col];
+                const double zz = zrow[row], ww = wrow[row];
                 w[t][r] = ww;
                 v[t][r] = zz - ww;
             }
@@ -209,8 +209,8 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int row = 16 * t + 4 * r + kq;
-            zblk[row * 16 + col] = v[t][r] + w[t][r];
-            wblk[row * 16 + col] = w[t][r];
+            zrow[row] = v[t][r] + w[t][r];
+            wrow[row] = w[t][r];
         }
     if (kq == 0 && live) {
         p.iters[inst] = it;

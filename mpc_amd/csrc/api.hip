@@ -32,23 +32,31 @@ int ensure_batch(mpcqp_handle h, int B) {
 
 __global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int nu) {
     // one thread per (block of 16 instances, column); walk the rows forward by one stage
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= nblk * 16) return;
-    const int blk = idx >> 4, c = idx & 15;
-    double* zb = z + (size_t)blk * NP * 16 + c;
-    double* wb = w + (size_t)blk * NP * 16 + c;
-    for (int r = 0; r + nu < n; ++r) {
-        zb[(size_t)r * 16] = zb[(size_t)(r + nu) * 16];
-        wb[(size_t)r * 16] = wb[(size_t)(r + nu) * 16];
+    // one 64-lane wave per instance; rows move forward by one stage (nu rows), the last stage repeats
+    const int inst = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (inst >= nblk) return;
+    double* zb = z + (size_t)inst * NP;
+    double* wb = w + (size_t)inst * NP;
+    double zv[2], wv[2];
+    for (int q = 0; q < 2; ++q) {
+        const int r = lane + 64 * q;
+        const int src = (r + nu < n) ? r + nu : r;
+        zv[q] = r < n ? zb[src] : 0.0;
+        wv[q] = r < n ? wb[src] : 0.0;
     }
-    // last stage repeats itself (z and w keep their old last-stage values)
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int q = 0; q < 2; ++q) {
+        const int r = lane + 64 * q;
+        if (r < n) { zb[r] = zv[q]; wb[r] = wv[q]; }
+    }
 }
 
 __global__ void unblock_kernel(const double* zb, double* out, int B, int NP, int n) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (size_t)B * n) return;
     const int inst = (int)(idx / n), j = (int)(idx % n);
-    out[idx] = zb[((size_t)(inst >> 4) * NP + j) * 16 + (inst & 15)];
+    out[idx] = zb[(size_t)inst * NP + j];
 }
 
 }  // namespace
@@ -61,7 +69,7 @@ void mpcqp_default_solve_opts(mpcqp_solve_opts* o) {
     if (!o) return;
     o->max_iter = 25; o->min_iter = 10; o->check_every = 5;
     o->eps_abs = 1e-6; o->eps_rel = 1e-6; o->alpha = 1.6;
-    o->polish = 1; o->polish_refine = 1; o->polish_max_steps = 0; o->warm_start = 0; o->stages = 3;
+    o->polish = 1; o->polish_refine = -1; o->polish_max_steps = 0; o->warm_start = 0; o->stages = 3;
 }
 
 int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
@@ -88,6 +96,7 @@ int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
     A_(&h->d, n); A_(&h->Hs, n * n); A_(&h->M, n * n); A_(&h->Hi, n * n); A_(&h->W1, n * n);
     A_(&h->W2, n * std::max(n, nx + 1));
     A_(&h->Fs1, n * (nx + 1)); A_(&h->Ku1, n * (nx + 1));
+    A_(&h->FsT, (size_t)h->NP * (nx + 1)); A_(&h->KuT, (size_t)h->NP * (nx + 1));
     A_(&h->Mfrag, (size_t)h->NT * h->S * 64); A_(&h->Kbfrag, (size_t)h->NT * h->SX * 64);
     A_(&h->Kufrag, (size_t)h->NT * h->SX * 64);
     A_(&h->lbs, h->NP); A_(&h->ubs, h->NP); A_(&h->rho_dev, 4); A_(&h->flag_dev, 4);
@@ -100,7 +109,7 @@ int mpcqp_destroy(mpcqp_handle h) {
     if (!h) return MPCQP_OK;
     (void)hipSetDevice(h->dev);
     void* ptrs[] = {h->Gam, h->QG, h->Phi, h->H, h->F, h->f0, h->d, h->Hs, h->M, h->Hi, h->W1, h->W2, h->Fs1,
-                    h->Ku1, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev,
+                    h->Ku1, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev,
                     h->z, h->w, h->it_ws, h->rp_ws, h->rd_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -150,12 +159,13 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     TRY(launch_factor(h, opts ? opts->rho : 0.0, st));
     // set-up call: fetch rho and the failure flag (the only host synchronisation besides create)
-    double r3[3]; int flag = 0;
+    double r3[4]; int flag = 0;
     HIPCHK(h, hipMemcpyAsync(r3, h->rho_dev, sizeof(r3), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipMemcpyAsync(&flag, h->flag_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     if (flag) { h->err = "factor: H is not positive definite (Cholesky pivot <= 0)"; return MPCQP_ENUMERIC; }
     h->rho = r3[0];
+    h->inv_resid = r3[3];
     h->factored = true; h->has_state = false;
     return MPCQP_OK;
 }
@@ -185,9 +195,8 @@ int mpcqp_shift(mpcqp_handle h, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->has_state) { h->err = "shift: no solution state yet"; return MPCQP_ESTATE; }
     HIPCHK(h, hipSetDevice(h->dev));
-    const int nblk = ceil_div(h->Blast, 16);
-    hipLaunchKernelGGL(shift_kernel, dim3(ceil_div(nblk * 16, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       h->z, h->w, nblk, h->NP, h->n, h->dims.nu);
+    hipLaunchKernelGGL(shift_kernel, dim3(ceil_div(h->Blast, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h->z, h->w, h->Blast, h->NP, h->n, h->dims.nu);
     HIPCHK(h, hipGetLastError());
     return MPCQP_OK;
 }

@@ -35,15 +35,17 @@ struct mpcqp_handle_s {
     double *d = nullptr, *Hs = nullptr, *M = nullptr, *Hi = nullptr, *W1 = nullptr, *W2 = nullptr;
     double *Fs1 = nullptr;      // (n, nx+1): [Fs | f0s]   qs = Fs1 [x0;1]
     double *Ku1 = nullptr;      // (n, nx+1): [Ku | ku]    x_unc = Ku1 [x0;1]
+    double *FsT = nullptr, *KuT = nullptr;   // the same two maps transposed, (nx+1, NP): coalesced per-row reads
     double *Mfrag = nullptr, *Kbfrag = nullptr, *Kufrag = nullptr;
     double *lbs = nullptr, *ubs = nullptr;                  // (NP) scaled bounds, padded rows = 0
     double *rho_dev = nullptr;  // [0] rho, [1] lambda_max est, [2] lambda_min est
     int *flag_dev = nullptr;    // [0] != 0: factorisation failed
     double rho = 0.0;
+    double inv_resid = 0.0;     // max |Hs Hi - I|: decides whether the polish refines by default
     // per-batch workspace (grow only)
     int Bcap = 0;               // capacity in instances (multiple of 64)
     int Blast = 0;              // batch of the last solve (for shift / warm start)
-    double *z = nullptr, *w = nullptr;     // blocked [Bcap/16][NP][16]
+    double *z = nullptr, *w = nullptr;     // [Bcap][NP] row-major, scaled variables
     int *it_ws = nullptr; double *rp_ws = nullptr, *rd_ws = nullptr;
     bool assembled = false, factored = false, has_state = false;
     std::string err;

@@ -14,7 +14,7 @@ namespace {
 
 struct FacParams {
     const double *H, *F, *f0, *umin, *umax;
-    double *d, *Hs, *M, *Hi, *W1, *W2, *Fs1, *Ku1, *Mfrag, *Kbfrag, *Kufrag, *lbs, *ubs, *rho_dev;
+    double *d, *Hs, *M, *Hi, *W1, *W2, *Fs1, *Ku1, *FsT, *KuT, *Mfrag, *Kbfrag, *Kufrag, *lbs, *ubs, *rho_dev;
     int* flag;
     int n, nx, nu, NT, S, SX, per_stage;
     double rho_in;
@@ -126,7 +126,26 @@ __global__ __launch_bounds__(256) void factor_kernel(FacParams f) {
         f.Ku1[idx] = su;
         Kb1[idx] = sb;
     }
+    // how far the explicit inverse is from exact: max |Hs Hi - I| (the polish refines if this is large)
+    {
+        double e = 0.0;
+        for (int idx = tid; idx < n * n; idx += 256) {
+            const int i = idx / n, j = idx % n;
+            double sacc = (i == j) ? -1.0 : 0.0;
+            for (int k = 0; k < n; ++k) sacc += f.Hs[(size_t)i * n + k] * f.Hi[(size_t)k * n + j];
+            e = fmax(e, fabs(sacc));
+        }
+        red[tid] = e; __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) { if (tid < sft) red[tid] = fmax(red[tid], red[tid + sft]); __syncthreads(); }
+        if (tid == 0) f.rho_dev[3] = red[0];
+        __syncthreads();
+    }
     const int NP = 16 * f.NT;
+    for (int idx = tid; idx < NP * nx1; idx += 256) {
+        const int c = idx / NP, i = idx % NP;
+        f.FsT[idx] = i < n ? f.Fs1[(size_t)i * nx1 + c] : 0.0;
+        f.KuT[idx] = i < n ? f.Ku1[(size_t)i * nx1 + c] : 0.0;
+    }
     for (int i = tid; i < NP; i += 256) {
         double lo = 0.0, hi = 0.0;
         if (i < n) {
@@ -158,7 +177,7 @@ int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
     FacParams f;
     f.H = h->H; f.F = h->F; f.f0 = h->f0; f.umin = h->umin; f.umax = h->umax;
     f.d = h->d; f.Hs = h->Hs; f.M = h->M; f.Hi = h->Hi; f.W1 = h->W1; f.W2 = h->W2;
-    f.Fs1 = h->Fs1; f.Ku1 = h->Ku1; f.Mfrag = h->Mfrag; f.Kbfrag = h->Kbfrag; f.Kufrag = h->Kufrag;
+    f.Fs1 = h->Fs1; f.Ku1 = h->Ku1; f.FsT = h->FsT; f.KuT = h->KuT; f.Mfrag = h->Mfrag; f.Kbfrag = h->Kbfrag; f.Kufrag = h->Kufrag;
     f.lbs = h->lbs; f.ubs = h->ubs; f.rho_dev = h->rho_dev; f.flag = h->flag_dev;
     f.n = h->n; f.nx = h->dims.nx; f.nu = h->dims.nu; f.NT = h->NT; f.S = h->S; f.SX = h->SX;
     f.per_stage = h->per_stage; f.rho_in = rho;

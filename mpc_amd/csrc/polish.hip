@@ -17,16 +17,16 @@
 // the explicit inverse.
 //
 // Mapping: one wave per instance, lane j owns rows j and j+64 (n <= 128); the packed Cholesky factor
-// of S lives in LDS (KMAX = 48 rows in the fast pass; instances that need more are redone by a
+// of S lives in LDS (KMAX = 32 rows in the fast pass; instances that need more are redone by a
 // second launch with KMAX = 128 and one wave per workgroup).  No workgroup barriers.
 #include "common.h"
 
 namespace {
 
 struct PolParams {
-    const double *Hs, *Hi, *Fs1, *Ku1, *lbs, *ubs, *d;
+    const double *Hs, *Hi, *FsT, *KuT, *lbs, *ubs, *d;     // FsT, KuT: (nx+1, NP)
     const double* x0;
-    double *z, *w;                 // blocked [ceil(B/16)][NP][16]
+    double *z, *w;                 // [Bcap][NP] row-major
     const int* it_ws; const double *rp_ws, *rd_ws;
     const int* cv_ws;              // [B]: 1 if ADMM met its eps criterion
     int* need_big;                 // [B]: 1 if the fast pass overflowed KMAX
@@ -63,17 +63,26 @@ __device__ __forceinline__ double& Lat(WaveLds<KMAX>& s, int i, int m) { return 
 // Cholesky of S = Hi[A,A] (k x k) into s.L.  Returns false on a non-positive pivot.
 template <int KMAX>
 __device__ bool chol_S(WaveLds<KMAX>& s, const double* Hi, int n, int k, int lane) {
+    // stage the lower triangle of S in place first, with every load in flight at once (one
+    // dependent L2 round trip instead of one per column)
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int i = lane + 64 * q;
+        if (i < k) {
+            const size_t ri = (size_t)(abs(s.A[i]) - 1) * n;
+            for (int c = 0; c <= i; ++c) Lat(s, i, c) = Hi[ri + (abs(s.A[c]) - 1)];
+        }
+    }
+    wave_sync();
     bool ok = true;
     for (int c = 0; c < k; ++c) {
-        const int ac = abs(s.A[c]) - 1;
         double t[2];
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = lane + 64 * q;
             t[q] = 0.0;
             if (i >= c && i < k) {
-                const int ai = abs(s.A[i]) - 1;
-                double v = Hi[(size_t)ai * n + ac];
+                double v = Lat(s, i, c);
                 for (int m = 0; m < c; ++m) v -= Lat(s, i, m) * Lat(s, c, m);
                 t[q] = v;
             }
@@ -81,6 +90,7 @@ __device__ bool chol_S(WaveLds<KMAX>& s, const double* Hi, int n, int k, int lan
         const double dcc = row_get(t[0], t[1], c);
         if (!(dcc > 0.0)) { ok = false; break; }
         const double dinv = 1.0 / sqrt(dcc);
+        wave_sync();        // every lane has read row c's old entries before they are overwritten
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int i = lane + 64 * q;
@@ -139,29 +149,38 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
     const int inst = blockIdx.x * WAVES + wave;
     if (inst >= p.B) return;
     if (p.pass == 1 && p.need_big[inst] == 0) return;
-    const int n = p.n, nx1 = p.nx + 1;
+    const int n = p.n;
     const double* Hi = p.Hi;
 
     // ---- per-row data ---------------------------------------------------------------------
     double xu[2], qs[2], x[2], lo[2], hi[2], lam[2];
     int side[2];
-    double* zb = p.z + ((size_t)(inst >> 4) * p.NP) * 16 + (inst & 15);
-    double* wb = p.w + ((size_t)(inst >> 4) * p.NP) * 16 + (inst & 15);
+    double* zb = p.z + (size_t)inst * p.NP;
+    double* wb = p.w + (size_t)inst * p.NP;
+    // x0 of this instance, one element per lane, broadcast on use
+    const double x0l = (lane < p.nx) ? p.x0[(size_t)inst * p.nx + lane] : 0.0;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        xu[q] = qs[q] = x[q] = lo[q] = hi[q] = lam[q] = 0.0;
+        side[q] = 0;
+    }
+    {
+        const bool in0 = lane < n, in1 = lane + 64 < n;
+        double su0 = in0 ? p.KuT[(size_t)p.nx * p.NP + lane] : 0.0, su1 = in1 ? p.KuT[(size_t)p.nx * p.NP + lane + 64] : 0.0;
+        double sq0 = in0 ? p.FsT[(size_t)p.nx * p.NP + lane] : 0.0, sq1 = in1 ? p.FsT[(size_t)p.nx * p.NP + lane + 64] : 0.0;
+        for (int c = 0; c < p.nx; ++c) {
+            const double xc = bcast(x0l, c);
+            if (in0) { su0 += p.KuT[(size_t)c * p.NP + lane] * xc; sq0 += p.FsT[(size_t)c * p.NP + lane] * xc; }
+            if (in1) { su1 += p.KuT[(size_t)c * p.NP + lane + 64] * xc; sq1 += p.FsT[(size_t)c * p.NP + lane + 64] * xc; }
+        }
+        xu[0] = su0; xu[1] = su1; qs[0] = sq0; qs[1] = sq1;
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
         const int j = lane + 64 * q;
-        xu[q] = qs[q] = x[q] = lo[q] = hi[q] = lam[q] = 0.0;
-        side[q] = 0;
         if (j < n) {
-            double su = p.Ku1[(size_t)j * nx1 + p.nx], sq = p.Fs1[(size_t)j * nx1 + p.nx];
-            for (int c = 0; c < p.nx; ++c) {
-                const double xc = p.x0[(size_t)inst * p.nx + c];
-                su += p.Ku1[(size_t)j * nx1 + c] * xc;
-                sq += p.Fs1[(size_t)j * nx1 + c] * xc;
-            }
-            xu[q] = su; qs[q] = sq;
             lo[q] = p.lbs[j]; hi[q] = p.ubs[j];
-            const double zz = zb[(size_t)j * 16], ww = wb[(size_t)j * 16];
+            const double zz = zb[j], ww = wb[j];
             x[q] = zz;
             lam[q] = p.rho * ww;
             side[q] = (zz >= hi[q] && ww > 0.0) ? 1 : ((zz <= lo[q] && ww < 0.0) ? -1 : 0);
@@ -412,7 +431,7 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int j = lane + 64 * q;
-            if (j < n) { x[q] = zb[(size_t)j * 16]; lam[q] = p.rho * wb[(size_t)j * 16]; }
+            if (j < n) { x[q] = zb[j]; lam[q] = p.rho * wb[j]; }
         }
         status = p.cv_ws[inst] ? MPCQP_SOLVED_INACCURATE : MPCQP_MAX_ITER;
     }
@@ -448,8 +467,8 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
             p.U[(size_t)inst * n + j] = dj * x[q];
             if (p.info.lam) p.info.lam[(size_t)inst * n + j] = lam[q] / dj;
             if (status == MPCQP_SOLVED) {       // keep the polished point as warm-start state
-                zb[(size_t)j * 16] = x[q];
-                wb[(size_t)j * 16] = lam[q] / p.rho;
+                zb[j] = x[q];
+                wb[j] = lam[q] / p.rho;
             }
         }
     }
@@ -478,17 +497,20 @@ int launch_pol(const PolParams& p, hipStream_t st) {
 int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
                       const mpcqp_solve_opts& o, hipStream_t st) {
     PolParams p;
-    p.Hs = h->Hs; p.Hi = h->Hi; p.Fs1 = h->Fs1; p.Ku1 = h->Ku1; p.lbs = h->lbs; p.ubs = h->ubs; p.d = h->d;
+    p.Hs = h->Hs; p.Hi = h->Hi; p.FsT = h->FsT; p.KuT = h->KuT; p.lbs = h->lbs; p.ubs = h->ubs; p.d = h->d;
     p.x0 = x0; p.z = h->z; p.w = h->w; p.it_ws = h->it_ws; p.rp_ws = h->rp_ws; p.rd_ws = h->rd_ws;
     p.need_big = h->it_ws + h->Bcap;      // int workspace: [iters | need_big | converged]
     p.cv_ws = h->it_ws + 2 * (size_t)h->Bcap;
     p.U = U;
     if (info) p.info = *info; else p.info = mpcqp_info{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     p.B = B; p.n = h->n; p.nx = h->dims.nx; p.NP = h->NP;
-    p.polish = o.polish; p.refine = o.polish_refine; p.max_steps = o.polish_max_steps > 0 ? o.polish_max_steps : 4 * h->n + 16;
+    p.polish = o.polish;
+    // refine < 0: automatic -- one step with Hs itself only if the explicit inverse is not accurate enough
+    p.refine = o.polish_refine >= 0 ? o.polish_refine : (h->inv_resid > 1e-9 ? 1 : 0); p.max_steps = o.polish_max_steps > 0 ? o.polish_max_steps : 4 * h->n + 16;
     p.rho = h->rho;
     p.pass = 0;
-    int rc = launch_pol<48, 4>(p, st);
+    if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
+    int rc = launch_pol<32, 4>(p, st);
     if (rc == 0 && o.polish) { p.pass = 1; rc = launch_pol<128, 1>(p, st); }
     if (rc != 0) { h->err = std::string("polish launch: ") + hipGetErrorString((hipError_t)rc); return MPCQP_EHIP; }
     return MPCQP_OK;
