@@ -113,3 +113,89 @@ def test_admm_only_matches_restatement():
     zd = pl.get("z", batch=48).cpu().numpy(); wd = pl.get("w", batch=48).cpu().numpy()
     assert np.abs(zd - z).max() <= 1e-7 * np.abs(z).max()
     assert np.abs(wd - w).max() <= 1e-7 * max(np.abs(w).max(), 1e-12)
+
+
+def test_ltv_references_and_per_stage_bounds():
+    """Time-varying (A_k, B_k), non-zero x_ref/u_ref, bounds that differ per stage."""
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_box_qp
+    rng = np.random.default_rng(5)
+    nx, nu, N, B = 5, 2, 12, 40
+    A = np.eye(nx)[None] + 0.15 * rng.standard_normal((N, nx, nx))
+    Bm = rng.standard_normal((N, nx, nu))
+    Q = np.diag(rng.uniform(0.5, 2, nx)); R = np.diag(rng.uniform(0.05, 0.2, nu)); P = 3 * Q
+    xr = rng.standard_normal((N, nx)); ur = 0.1 * rng.standard_normal((N, nu))
+    umin = -rng.uniform(0.2, 1.0, (N, nu)); umax = rng.uniform(0.2, 1.0, (N, nu))
+    x0 = rng.standard_normal((B, nx))
+    pl = Planner(nx, nu, N)
+    pl.set_model(A, Bm).set_cost(Q, R, P, x_ref=xr, u_ref=ur).set_constraints(umin, umax)
+    U = pl.solve(x0).cpu().numpy().reshape(B, -1)
+    assert (pl.info.status.cpu().numpy() == 0).all()
+    prob = dict(N=N, nx=nx, nu=nu, A=A, B=Bm, Q=Q, R=R, P=P)
+    H, F, f0 = mo.condense(prob, xr, ur)
+    assert np.abs(pl.get("f0").cpu().numpy() - f0).max() <= 1e-12 * np.abs(f0).max()
+    assert np.abs(pl.get("H").cpu().numpy() - H).max() <= 1e-12 * np.abs(H).max()
+    obj = pl.info.obj.cpu().numpy()
+    for i in range(0, B, 4):
+        s = solve_box_qp(H, F @ x0[i] + f0, umin.ravel(), umax.ravel())
+        assert _rel(U[i], s["x"]) <= PRIMAL_RTOL
+        assert abs(obj[i] - s["primal objective"]) <= OBJ_RTOL * abs(s["primal objective"])
+
+
+def test_shift_and_warm_start():
+    """Receding horizon: shift() moves the kept state one stage forward (last stage repeated); a
+    warm-started solve returns the same minimiser as a cold one."""
+    from mpc_amd.configs import make_config
+    prob = make_config(3, batch=128, seed=21)
+    pl = _planner(prob)
+    x0 = prob["x0"]
+    U0 = pl.solve(x0).cpu().numpy()
+    n, nu = pl.n, pl.nu
+    z_before = pl.get("z", batch=128).cpu().numpy()
+    pl.shift()
+    z_after = pl.get("z", batch=128).cpu().numpy()
+    assert np.array_equal(z_after[:, : n - nu], z_before[:, nu:])
+    assert np.array_equal(z_after[:, n - nu:], z_before[:, n - nu:])
+    # closed loop: apply u_0, step the model, solve again warm and cold
+    x1 = x0 @ prob["A"].T + U0[:, 0, :] @ prob["B"].T
+    Uw = pl.solve(x1, warm_start=True).cpu().numpy()
+    steps_w = pl.info.polish_steps.cpu().numpy().astype(float).mean()
+    assert (pl.info.status.cpu().numpy() == 0).all()
+    Uc = pl.solve(x1, warm_start=False).cpu().numpy()
+    steps_c = pl.info.polish_steps.cpu().numpy().astype(float).mean()
+    assert np.abs(Uw - Uc).max() <= 1e-9 * max(1.0, np.abs(Uc).max())
+    assert steps_w <= steps_c + 0.5
+    with pytest.raises(ValueError):
+        pl.solve(x1[:64], warm_start=True)          # state belongs to a different batch size
+
+
+def test_error_conventions():
+    """Failures surface as ordinary Exception subclasses (SE3Planner.py:107,198 relies on that)."""
+    from mpc_amd.planner import Planner
+    pl = Planner(2, 1, 5)
+    with pytest.raises(RuntimeError):
+        pl.solve(np.zeros((1, 2)))                  # nothing set up
+    pl.set_model(np.eye(2), np.ones((2, 1)))
+    pl.set_cost(-np.eye(2), -np.eye(1))             # not PD
+    pl.set_constraints([-1.0], [1.0])
+    with pytest.raises(ArithmeticError):
+        pl.solve(np.zeros((1, 2)))
+    with pytest.raises(ValueError):
+        pl.set_cost(np.eye(3), np.eye(1))
+    with pytest.raises(NotImplementedError):
+        pl.set_constraints([-1.0], [1.0], x_min=[0, 0])
+    big = Planner(2, 2, 100)                        # N*nu = 200 > 128
+    big.set_model(np.eye(2), np.eye(2)).set_cost(np.eye(2), np.eye(2)).set_constraints([-1, -1], [1, 1])
+    with pytest.raises(NotImplementedError):
+        big.solve(np.zeros((1, 2)))
+
+
+def test_ragged_and_tiny_batches():
+    from mpc_amd.configs import make_config
+    prob = make_config(3, batch=131, seed=2)
+    pl = _planner(prob)
+    Uall = pl.solve(prob["x0"]).cpu().numpy()
+    for b in (1, 15, 17, 63, 65):
+        Ub = pl.solve(prob["x0"][:b]).cpu().numpy()
+        assert np.abs(Ub - Uall[:b]).max() <= 1e-9 * np.abs(Uall).max(), b
