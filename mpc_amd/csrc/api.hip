@@ -22,6 +22,7 @@ int ensure_batch(mpcqp_handle h, int B) {
     if (need <= h->Bcap) return MPCQP_OK;
     TRY(dev_alloc(h, &h->z, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->w, (size_t)need * h->NP));
+    TRY(dev_alloc(h, &h->b0ws, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->it_ws, (size_t)need * 3));
     TRY(dev_alloc(h, &h->rp_ws, (size_t)need));
     TRY(dev_alloc(h, &h->rd_ws, (size_t)need));
@@ -110,7 +111,7 @@ int mpcqp_destroy(mpcqp_handle h) {
     (void)hipSetDevice(h->dev);
     void* ptrs[] = {h->Gam, h->QG, h->Phi, h->H, h->F, h->f0, h->d, h->Hs, h->M, h->Hi, h->W1, h->W2, h->Fs1,
                     h->Ku1, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev,
-                    h->z, h->w, h->it_ws, h->rp_ws, h->rd_ws};
+                    h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return MPCQP_OK;

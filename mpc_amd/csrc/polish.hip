@@ -183,7 +183,11 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
             const double zz = zb[j], ww = wb[j];
             x[q] = zz;
             lam[q] = p.rho * ww;
-            side[q] = (zz >= hi[q] && ww > 0.0) ? 1 : ((zz <= lo[q] && ww < 0.0) ? -1 : 0);
+            // (z, w) are recovered from the kernel's (v, c) state, so "at the bound" and "w != 0"
+            // hold up to rounding only
+            const double tz = 1e-9 * fmax(1.0, fmax(fabs(hi[q]), fabs(lo[q])));
+            const double tw = 1e-12 * fmax(1.0, fabs(zz));
+            side[q] = (zz >= hi[q] - tz && ww > tw) ? 1 : ((zz <= lo[q] + tz && ww < -tw) ? -1 : 0);
         }
     }
 
@@ -431,7 +435,7 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int j = lane + 64 * q;
-            if (j < n) { x[q] = zb[j]; lam[q] = p.rho * wb[j]; }
+            if (j < n) { x[q] = fmin(fmax(zb[j], lo[q]), hi[q]); lam[q] = p.rho * wb[j]; }
         }
         status = p.cv_ws[inst] ? MPCQP_SOLVED_INACCURATE : MPCQP_MAX_ITER;
     }
