@@ -125,6 +125,22 @@ int mpcqp_shift(mpcqp_handle h, void* stream);
  *        10 z (batch,n) scaled  11 w (batch,n) scaled                                    */
 int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, void* stream);
 
+/* -- dense QP: the reference's literal call  cvxopt.solvers.qp(P, q, G, h[, A, b]) ---------------------
+ * (CollocationBasedPlanner.py:59, LaunchPlannerQPFormulation.py:173, Launch3DPlanner.py:201,
+ *  CollocationBasedPlanner2D.py:359, SE3Planner.py:181,183) for `batch` independent QPs of equal shape:
+ *      min 1/2 x'Px + q'x   s.t.  Gx <= h (m rows),  Ax = b (p rows),   P symmetric PSD.
+ * All pointers are device pointers, row-major, instance-major ([batch][n*n], [batch][m*n] ...).
+ * Outputs: x [batch][n]; z [batch][m] (>= 0, may be NULL); y [batch][p] (may be NULL); obj [batch];
+ * status [batch]: 0 optimal, 1 step cap reached, 2 infeasible, 3 numerical failure (P not PSD);
+ * iters [batch]: active-set steps + 1000 * proximal iterations.
+ * The caller provides the scratch: `workspace` of batch * mpcqp_dense_workspace(n,m,p,&ni) doubles and
+ * `int_workspace` of batch * ni ints.  No handle, no allocation, asynchronous on `stream`. */
+long mpcqp_dense_workspace(int n, int m, int p, long* int_count);
+int  mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const double* P, const double* q,
+                       const double* G, const double* h, const double* A, const double* b,
+                       double* x, double* z, double* y, double* obj, int* status, int* iters,
+                       double* workspace, int* int_workspace, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

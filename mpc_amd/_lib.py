@@ -51,6 +51,8 @@ SYMBOLS = [
                               C.POINTER(SolveOpts), C.c_void_p]),
     ("mpcqp_shift", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_get", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
+    ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),
+    ("mpcqp_solve_dense", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 14 + [C.c_void_p]),
 ]
 
 _lib = None

@@ -1,0 +1,100 @@
+"""GPU parity of the literal reference boundary solvers.qp(P, q, G, h[, A, b]) on the reference scripts'
+own QPs (captured fixtures) and on seeded families, against the certified oracle."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+REF = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_*.npz")))
+
+
+def _check(P, q, G, h, A, b, x_ref, obj_ref, sol):
+    from oracle.qp_oracle import kkt_certificate
+    assert sol["status"] == "optimal"
+    x = np.array(sol["x"]).ravel()
+    scale = max(np.abs(x_ref).max(), 1e-300)
+    assert np.abs(x - x_ref).max() <= 1e-6 * scale
+    assert abs(sol["primal objective"] - obj_ref) <= 1e-8 * max(abs(obj_ref), 1e-300)
+    c = kkt_certificate(P, q, G, h, A, b, x, np.array(sol["z"]).ravel(), np.array(sol["y"]).ravel())
+    assert c["max"] <= 1e-9, c
+
+
+@pytest.mark.parametrize("path", REF, ids=[os.path.basename(p)[4:-4] for p in REF])
+def test_reference_qps(path):
+    from mpc_amd import solvers
+    d = np.load(path)
+    P, q, G, h, A, b = [d[k] for k in "PqGhAb"]
+    args = [solvers.matrix(P, tc="d"), solvers.matrix(q.reshape(-1, 1), tc="d"),
+            solvers.matrix(G, tc="d"), solvers.matrix(h.reshape(-1, 1), tc="d")]
+    if A.size:
+        args += [solvers.matrix(A, tc="d"), solvers.matrix(b.reshape(-1, 1), tc="d")]
+    sol = solvers.qp(*args)
+    _check(P, q, G, h, A if A.size else None, b if b.size else None, d["x"], float(d["objective"]), sol)
+    # the result object behaves like the reference uses it
+    xm = sol["x"]
+    assert xm.shape == (P.shape[0], 1) and isinstance(xm[0], float)
+    assert np.array(xm[0:2]).shape == (2, 1) or P.shape[0] < 2
+    assert np.allclose(G.dot(xm).ravel(), G @ np.array(xm).ravel())
+
+
+def test_reference_families_and_random():
+    from mpc_amd import solvers
+    from oracle import reference_qps as rq
+    from oracle.qp_oracle import solve_qp
+    cases = [rq.launch1d_qp(nodes=k, hDes=0.2) for k in (4, 8, 12, 20)] + [rq.launch3d_qp(nodes=k) for k in (6, 14)]
+    rng = np.random.default_rng(0)
+    for n, m, p in [(10, 20, 3), (40, 80, 10), (30, 10, 0), (100, 150, 40)]:
+        M = rng.standard_normal((n, n)); P = M @ M.T / n + 1e-3 * np.eye(n)
+        if n == 30:
+            P = M[:, :15] @ M[:, :15].T / n                  # singular PSD
+        q = rng.standard_normal(n); G = rng.standard_normal((m, n)); x0 = rng.standard_normal(n)
+        h = G @ x0 + rng.uniform(0, 1, m)
+        A = rng.standard_normal((p, n)) if p else None; b = A @ x0 if p else None
+        if n == 30:
+            G = np.vstack([G, np.eye(n), -np.eye(n)]); h = np.concatenate([h, 10 * np.ones(2 * n)])
+        cases.append((P, q, G, h, A, b))
+    for P, q, G, h, A, b in cases:
+        q = np.ravel(q); h = np.ravel(h); b = None if b is None else np.ravel(b)
+        s = solve_qp(P, q, G, h, A, b)
+        assert s["status"] == "optimal"
+        sol = solvers.qp(P, q.reshape(-1, 1), G, h.reshape(-1, 1), A, None if b is None else b.reshape(-1, 1))
+        _check(P, q, G, h, A, b, s["x"], s["primal objective"], sol)
+
+
+def test_status_and_errors():
+    from mpc_amd import solvers
+    P = np.eye(2); q = np.zeros(2)
+    G = np.array([[1.0, 0.0], [-1.0, 0.0]]); h = np.array([-1.0, -1.0])        # x0 <= -1 and x0 >= 1
+    assert solvers.qp(P, q, G, h)["status"] == "unknown"                      # infeasible: a status, not an exception
+    with pytest.raises(ArithmeticError):
+        solvers.qp(-np.eye(2), q, G, np.array([1.0, 1.0]))                    # not PSD
+    with pytest.raises(ValueError):
+        solvers.qp(np.eye(3), q)
+    sol = solvers.qp(P, np.array([1.0, -2.0]))                                # unconstrained
+    assert np.allclose(np.array(sol["x"]).ravel(), [-1.0, 2.0])
+    assert solvers.matrix([], tc="d").shape == (0, 1)                         # SE3Planner.py:152
+    solvers.options["show_progress"] = False
+
+
+def test_batched_dense_and_cost_builder():
+    import torch
+    from mpc_amd.helper_funcs import getQuadProgCostFunction
+    from mpc_amd.solvers import qp_batch
+    from oracle.qp_oracle import solve_qp
+    rng = np.random.default_rng(3)
+    B, n, m = 9, 18, 12
+    J = rng.standard_normal((B, 24, n)); c = rng.standard_normal((B, 24, 1)); W = np.stack([np.diag(rng.uniform(0.1, 2, 24))] * B)
+    Q, f = getQuadProgCostFunction(torch.as_tensor(J, device="cuda"), torch.as_tensor(c, device="cuda"),
+                                   torch.as_tensor(W, device="cuda"))
+    Qn, fn = getQuadProgCostFunction(J[0], c[0], W[0])
+    assert fn.shape == (n, 1) and np.allclose(Q[0].cpu().numpy(), Qn) and np.allclose(f[0].cpu().numpy(), fn)
+    G = rng.standard_normal((B, m, n)); h = rng.uniform(0.1, 1, (B, m))
+    r = qp_batch(Q, f[:, :, 0], G, h)
+    assert (r["status"].cpu().numpy() == 0).all()
+    X = r["x"].cpu().numpy()
+    for i in range(B):
+        s = solve_qp(Q[i].cpu().numpy(), f[i, :, 0].cpu().numpy(), G[i], h[i])
+        assert np.abs(X[i] - s["x"]).max() <= 1e-6 * max(np.abs(s["x"]).max(), 1e-300)
