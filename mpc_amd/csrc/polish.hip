@@ -42,7 +42,16 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-__device__ __forceinline__ double bcast(double v, int src) { return __shfl(v, src, 64); }
+// broadcast from a WAVE-UNIFORM source lane: two v_readlane_b32 instead of two ds_bpermute round trips
+__device__ __forceinline__ double bcast(double v, int src) {
+    const int sl = __builtin_amdgcn_readfirstlane(src);
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), sl);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), sl);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ int bcast_i(int v, int src) {
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(src));
+}
 
 // value owned by "row" i of a 2-slot per-lane vector (rows lane, lane+64)
 __device__ __forceinline__ double row_get(double v0, double v1, int i) {
@@ -54,6 +63,7 @@ struct WaveLds {
     double L[KMAX * (KMAX + 1) / 2];
     double xs[128];        // current x (scaled), indexable by row
     double gs[128];        // scratch vector indexable by row
+    double di[KMAX];       // 1 / L[c][c]
     int A[KMAX];           // active rows, signed: +(row+1) upper, -(row+1) lower
 };
 
@@ -95,6 +105,7 @@ __device__ bool chol_S(WaveLds<KMAX>& s, const double* Hi, int n, int k, int lan
         for (int q = 0; q < 2; ++q) {
             const int i = lane + 64 * q;
             if (i >= c && i < k) Lat(s, i, c) = (i == c) ? sqrt(dcc) : t[q] * dinv;
+            if (i == c) s.di[c] = dinv;
         }
         wave_sync();
     }
@@ -105,7 +116,7 @@ __device__ bool chol_S(WaveLds<KMAX>& s, const double* Hi, int n, int k, int lan
 template <int KMAX>
 __device__ __forceinline__ void fwd_solve(WaveLds<KMAX>& s, int k, int lane, double& v0, double& v1) {
     for (int c = 0; c < k; ++c) {
-        const double yc = row_get(v0, v1, c) / Lat(s, c, c);
+        const double yc = row_get(v0, v1, c) * s.di[c];
         if (lane == c) v0 = yc;
         if (lane + 64 == c) v1 = yc;
         if (lane > c && lane < k) v0 -= Lat(s, lane, c) * yc;
@@ -117,11 +128,30 @@ __device__ __forceinline__ void fwd_solve(WaveLds<KMAX>& s, int k, int lane, dou
 template <int KMAX>
 __device__ __forceinline__ void bwd_solve(WaveLds<KMAX>& s, int k, int lane, double& v0, double& v1) {
     for (int c = k - 1; c >= 0; --c) {
-        const double yc = row_get(v0, v1, c) / Lat(s, c, c);
+        const double yc = row_get(v0, v1, c) * s.di[c];
         if (lane == c) v0 = yc;
         if (lane + 64 == c) v1 = yc;
         if (lane < c) v0 -= Lat(s, c, lane) * yc;
         if (lane + 64 < c) v1 -= Lat(s, c, lane + 64) * yc;
+    }
+}
+
+
+// acc_q -= sum_a Hi[row(A_a)][lane + 64 q] * coef_a, with the list (rows) and the coefficients held in
+// list order in registers (lane a <-> member a): row index and coefficient become scalars by readlane,
+// so the loop is scalar address arithmetic + coalesced row loads + FMAs, with no LDS in it.
+template <int KMAX>
+__device__ __forceinline__ void rows_accum(const WaveLds<KMAX>& s, const double* Hi, int n, int k, int lane,
+                                           double c0, double c1, double& acc0, double& acc1) {
+    const int a0 = lane < k ? abs(s.A[lane]) - 1 : 0;
+    const int a1 = lane + 64 < k ? abs(s.A[lane + 64]) - 1 : 0;
+    const bool in0 = lane < n, in1 = lane + 64 < n;
+    for (int a = 0; a < k; ++a) {
+        const int r = a < 64 ? bcast_i(a0, a) : bcast_i(a1, a - 64);
+        const double cf = a < 64 ? bcast(c0, a) : bcast(c1, a - 64);
+        const double* row = Hi + (size_t)r * n;
+        if (in0) acc0 -= row[lane] * cf;
+        if (in1) acc1 -= row[lane + 64] * cf;
     }
 }
 
@@ -225,17 +255,10 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
             const bool anyneg = __any(neg0 || neg1);
             if (!anyneg) {
                 // x = xu - Hi[:,A] lam_A, exact bounds on A
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int j = lane + 64 * q;
-                    double acc = xu[q];
-                    if (j < n)
-                        for (int a = 0; a < k; ++a) {
-                            const int r = abs(s.A[a]) - 1;
-                            acc -= Hi[(size_t)r * n + j] * s.gs[r];
-                        }
-                    x[q] = side[q] > 0 ? hi[q] : (side[q] < 0 ? lo[q] : acc);
-                }
+                double acc0 = xu[0], acc1 = xu[1];
+                rows_accum(s, Hi, n, k, lane, v0, v1, acc0, acc1);
+                x[0] = side[0] > 0 ? hi[0] : (side[0] < 0 ? lo[0] : acc0);
+                x[1] = side[1] > 0 ? hi[1] : (side[1] < 0 ? lo[1] : acc1);
                 break;
             }
             // release: row-order test on lam sign
@@ -317,18 +340,14 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
                 const bool full = (t2 <= t1);
                 const double t = full ? t2 : t1;
                 // primal direction z_j = sp Hi[p][j] - sum_a Hi[A_a][j] r_a
-#pragma unroll
-                for (int q = 0; q < 2; ++q) {
-                    const int j = lane + 64 * q;
-                    if (j < n) {
-                        double zj = sp * Hi[(size_t)pr * n + j];
-                        for (int a = 0; a < k; ++a) {
-                            const int r = abs(s.A[a]) - 1;
-                            zj -= Hi[(size_t)r * n + j] * s.gs[r];
-                        }
-                        if (side[q] == 0) x[q] -= t * zj;
-                        lam[q] -= t * rr[q];
-                    }
+                {
+                    double z0 = lane < n ? sp * Hi[(size_t)pr * n + lane] : 0.0;
+                    double z1 = lane + 64 < n ? sp * Hi[(size_t)pr * n + lane + 64] : 0.0;
+                    rows_accum(s, Hi, n, k, lane, r0, r1, z0, z1);
+                    if (side[0] == 0) x[0] -= t * z0;
+                    if (side[1] == 0) x[1] -= t * z1;
+                    lam[0] -= t * rr[0];
+                    lam[1] -= t * rr[1];
                 }
                 accl += sp * t;
                 ++steps;
@@ -337,7 +356,7 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
                     // append row k of the factor: [l, sqrt(d2)]
                     if (lane < k) Lat(s, k, lane) = l0;
                     if (lane + 64 < k) Lat(s, k, lane + 64) = l1;
-                    if (lane == 0) { Lat(s, k, k) = sqrt(d2); s.A[k] = sp * (pr + 1); }
+                    if (lane == 0) { Lat(s, k, k) = sqrt(d2); s.di[k] = 1.0 / sqrt(d2); s.A[k] = sp * (pr + 1); }
                     ++k;
 #pragma unroll
                     for (int q = 0; q < 2; ++q)
@@ -402,18 +421,11 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
                     if (lane < k) s.gs[abs(s.A[lane]) - 1] = v0;
                     if (lane + 64 < k) s.gs[abs(s.A[lane + 64]) - 1] = v1;
                     wave_sync();
-#pragma unroll
-                    for (int q = 0; q < 2; ++q) {
-                        const int j = lane + 64 * q;
-                        if (j < n) {
-                            double acc = dx[q];
-                            for (int a = 0; a < k; ++a) {
-                                const int r = abs(s.A[a]) - 1;
-                                acc -= Hi[(size_t)r * n + j] * s.gs[r];
-                            }
-                            if (side[q] == 0) x[q] += acc;
-                            else lam[q] += s.gs[j];
-                        }
+                    {
+                        double a0 = dx[0], a1 = dx[1];
+                        rows_accum(s, Hi, n, k, lane, v0, v1, a0, a1);
+                        if (side[0] == 0) x[0] += a0; else lam[0] += s.gs[lane];
+                        if (side[1] == 0) x[1] += a1; else lam[1] += s.gs[lane + 64];
                     }
                 } else {
                     x[0] += dx[0]; x[1] += dx[1];
