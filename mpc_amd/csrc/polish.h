@@ -1,0 +1,24 @@
+// Parameters shared by the two polish kernels (polish.hip: one wave per instance, any active-set size;
+// polish_quad.hip: four lanes per instance, Hs^-1 resident in LDS, small active sets).
+#pragma once
+#include "common.h"
+
+struct PolParams {
+    const double *Hs, *Hi, *FsT, *KuT, *lbs, *ubs, *d;     // FsT, KuT: (nx+1, NP)
+    const double* x0;
+    double *z, *w;                 // [Bcap][NP] row-major
+    const int* it_ws; const double *rp_ws, *rd_ws;
+    const int* cv_ws;              // [B]: 1 if ADMM met its eps criterion
+    int* need_big;                 // [B]: 1 if the fast pass overflowed KMAX
+    double* U;                     // [B][n]
+    mpcqp_info info;
+    int B, n, nx, NP;
+    int polish, refine, max_steps, pass;   // pass 0: fast, 1: big
+    double rho;
+    const int *qin, *qin_count;    // instance queue to take the work from (nullptr: instances 0..B-1)
+    int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)
+    unsigned long long* prof;      // debugging only (POLISH_PROF builds): per-phase cycle sums, else nullptr
+};
+
+// fast path; returns MPCQP_ENOTIMPL if the shape does not fit it (the caller then uses the wave kernel)
+int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st);

@@ -20,22 +20,11 @@
 // of S lives in LDS (KMAX = 32 rows in the fast pass; instances that need more are redone by a
 // second launch with KMAX = 128 and one wave per workgroup).  No workgroup barriers.
 #include "common.h"
+#include "polish.h"
+#include <cstdlib>
 
 namespace {
 
-struct PolParams {
-    const double *Hs, *Hi, *FsT, *KuT, *lbs, *ubs, *d;     // FsT, KuT: (nx+1, NP)
-    const double* x0;
-    double *z, *w;                 // [Bcap][NP] row-major
-    const int* it_ws; const double *rp_ws, *rd_ws;
-    const int* cv_ws;              // [B]: 1 if ADMM met its eps criterion
-    int* need_big;                 // [B]: 1 if the fast pass overflowed KMAX
-    double* U;                     // [B][n]
-    mpcqp_info info;
-    int B, n, nx, NP;
-    int polish, refine, max_steps, pass;   // pass 0: fast, 1: big
-    double rho;
-};
 
 __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -171,14 +160,9 @@ __device__ int build_list(WaveLds<KMAX>& s, const int (&side)[2], int lane) {
     return k;
 }
 
-template <int KMAX, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    WaveLds<KMAX>& s = reinterpret_cast<WaveLds<KMAX>*>(smem)[wave];
-    const int inst = blockIdx.x * WAVES + wave;
-    if (inst >= p.B) return;
-    if (p.pass == 1 && p.need_big[inst] == 0) return;
+// one instance, one wave
+template <int KMAX>
+__device__ void polish_wave(const PolParams& p, const int inst, WaveLds<KMAX>& s, const int lane) {
     const int n = p.n;
     const double* Hi = p.Hi;
 
@@ -499,12 +483,31 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
 }
 
 template <int KMAX, int WAVES>
-int launch_pol(const PolParams& p, hipStream_t st) {
+__global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    WaveLds<KMAX>& s = reinterpret_cast<WaveLds<KMAX>*>(smem)[wave];
+    if (p.qin) {            // leftovers of the fast path: grid-stride over the device-side queue
+        const int cnt = *p.qin_count;
+        for (int qi = blockIdx.x * WAVES + wave; qi < cnt; qi += gridDim.x * WAVES) {
+            polish_wave<KMAX>(p, p.qin[qi], s, lane);
+            wave_sync();
+        }
+        return;
+    }
+    const int inst = blockIdx.x * WAVES + wave;
+    if (inst >= p.B) return;
+    if (p.pass == 1 && p.need_big[inst] == 0) return;
+    polish_wave<KMAX>(p, inst, s, lane);
+}
+
+template <int KMAX, int WAVES>
+int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
     const size_t lds = sizeof(WaveLds<KMAX>) * WAVES;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_box_kernel<KMAX, WAVES>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((polish_box_kernel<KMAX, WAVES>), dim3(ceil_div(p.B, WAVES)), dim3(64 * WAVES), lds, st, p);
+    hipLaunchKernelGGL((polish_box_kernel<KMAX, WAVES>), dim3(blocks > 0 ? blocks : ceil_div(p.B, WAVES)), dim3(64 * WAVES), lds, st, p);
     return (int)hipGetLastError();
 }
 
@@ -524,10 +527,43 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     // refine < 0: automatic -- one step with Hs itself only if the explicit inverse is not accurate enough
     p.refine = o.polish_refine >= 0 ? o.polish_refine : (h->inv_resid > 1e-9 ? 1 : 0); p.max_steps = o.polish_max_steps > 0 ? o.polish_max_steps : 4 * h->n + 16;
     p.rho = h->rho;
+    p.prof = nullptr;
+#ifdef POLISH_PROF
+    static unsigned long long* profbuf = nullptr;
+    if (!profbuf) { (void)hipMalloc(&profbuf, 16 * 8); }
+    (void)hipMemsetAsync(profbuf, 0, 16 * 8, st);
+    p.prof = profbuf;
+#endif
     p.pass = 0;
+    p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
-    int rc = launch_pol<32, 4>(p, st);
-    if (rc == 0 && o.polish) { p.pass = 1; rc = launch_pol<128, 1>(p, st); }
+    // int workspace beyond [iters | need_big | converged]: two instance queues and their counters
+    int* q1 = h->it_ws + 3 * (size_t)h->Bcap;
+    int* q2 = q1 + h->Bcap;
+    int* counters = q2 + h->Bcap;
+    // small active sets (the usual case): eight lanes per instance with Hs^-1 in LDS, two passes (polish_quad.hip);
+    // what those cannot finish is queued in q2 for the wave-per-instance kernel.  Shapes the fast path does not
+    // take (refinement requested, polish off, n > 128) run the wave-per-instance kernel on the whole batch.
+    int rc = launch_polish_quad(p, q1, q2, counters, st);
+#ifdef POLISH_PROF
+    if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {
+        unsigned long long pr[16]; int cn[2];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(pr, profbuf, sizeof(pr), hipMemcpyDeviceToHost);
+        (void)hipMemcpy(cn, counters, sizeof(cn), hipMemcpyDeviceToHost);
+        const double nw = (double)ceil_div(B, 64) * 8;
+        fprintf(stderr, "[polish prof] queued after pass A %d, after pass B %d of %d; per wave cycles (A+B): stage %.0f xu %.0f warm-build %.0f warm-lam %.0f "
+                "xeval %.0f main %.0f out %.0f | build iters %.1f inner iters %.1f\n", cn[0], cn[1], B,
+                pr[0] / nw, pr[1] / nw, pr[2] / nw, pr[3] / nw, pr[4] / nw, pr[5] / nw, pr[6] / nw, pr[7] / nw, pr[8] / nw);
+    }
+#endif
+    if (rc == 0) {
+        p.pass = 1; p.qin = q2; p.qin_count = counters + 1;
+        rc = launch_pol<128, 1>(p, st, 512);
+    } else if (rc < 0) {
+        rc = launch_pol<32, 4>(p, st);
+        if (rc == 0 && o.polish) { p.pass = 1; rc = launch_pol<128, 1>(p, st); }
+    }
     if (rc != 0) { h->err = std::string("polish launch: ") + hipGetErrorString((hipError_t)rc); return MPCQP_EHIP; }
     return MPCQP_OK;
 }

@@ -1,0 +1,729 @@
+// Polish, fast path: the same dual active-set method as polish.hip (Goldfarb-Idnani on the Schur
+// complement S = Hi[A,A] of the shared inverse Hi = Hs^-1, warm-started from the ADMM iterate), laid
+// out for what the workload looks like.  On condensed MPC QPs the optimal active set is small
+// (config 3, measured: mean 7.4 of 120 bounds, 97.7 % of instances <= 16, 99.98 % <= 24), so the
+// per-instance arithmetic is a few thousand flops and the one-wave-per-instance kernel spends its
+// time issuing 64-wide instructions for 7-element vectors and walking Cholesky columns one by one.
+//
+// Mapping: EIGHT lanes per instance (half a DPP row), 64 instances per 512-thread workgroup, two
+// waves per SIMD.
+//   * Hi (n x n, odd row stride) is staged ONCE per workgroup into LDS and serves all 64 instances;
+//     it is symmetric, so "column p restricted to my rows" is a contiguous row read.
+//   * lane g of the group owns the row pairs (16j+2g, 16j+2g+1), j < RP, of x in registers.
+//   * Instead of a Cholesky factor the group keeps W = S^-1 itself (k <= KMAX), rows 8i+g in lane g,
+//     embedded in a KMAX x KMAX matrix whose unused rows/columns are zero.  Every update is then a
+//     matrix-vector product or a rank-one update with compile-time register indices and no
+//     column-by-column dependency chain:
+//         add p   :  r = W h,  d2 = Hi[p,p] - h'r,  W += u u'/d2  with u = [r; -1 at the new slot]
+//         drop j  :  W -= W[:,j] W[j,:] / W[j,j], then row/column j are zeroed and the slot is free
+//     (block-inverse / Sherman-Morrison forms of what polish.hip does with its factor; S is a
+//     principal submatrix of Hi, cond <= cond(Hs), and there are at most a few dozen updates).
+//     Vectors a whole group needs (r, W[j,:], the row list) are exchanged through a per-instance LDS
+//     scratch; scalars are reduced with DPP (quad_perm + row_half_mirror).
+//   * the 8 instances of a wave advance in lock-step (one add/drop per round, predicated).
+// Instances whose active set outgrows KMAX (or that hit a numerical guard) are flagged in need_big and
+// redone from the untouched ADMM iterate by the wave-per-instance kernel (polish.hip).
+//
+// Reference counterpart: as polish.hip -- the accuracy of soln['x'] (LaunchPlannerQPFormulation.py:174).
+#include "polish.h"
+
+namespace {
+
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;     // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int DPP_HMIRROR = 0x141;                  // row_half_mirror: lane i <-> 7-i of each 8
+
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_d(double v) {
+    return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
+}
+__device__ __forceinline__ void wsync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+// sum over the 8 lanes of a group, result in all of them
+__device__ __forceinline__ double grp_sum(double v) {
+    v += dpp_d<DPP_XOR1>(v);
+    v += dpp_d<DPP_XOR2>(v);
+    v += dpp_d<DPP_HMIRROR>(v);
+    return v;
+}
+template <int CTRL>
+__device__ __forceinline__ void min_step(double& t, int& j) {
+    const double ot = dpp_d<CTRL>(t); const int oj = dpp_i<CTRL>(j);
+    if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
+}
+// (smallest t, its index; ties to the lower index) over the group
+__device__ __forceinline__ void grp_min(double& t, int& j) {
+    min_step<DPP_XOR1>(t, j); min_step<DPP_XOR2>(t, j); min_step<DPP_HMIRROR>(t, j);
+}
+template <int CTRL>
+__device__ __forceinline__ void imin_step(int& j) { const int oj = dpp_i<CTRL>(j); j = oj < j ? oj : j; }
+__device__ __forceinline__ int grp_imin(int j) {
+    imin_step<DPP_XOR1>(j); imin_step<DPP_XOR2>(j); imin_step<DPP_HMIRROR>(j);
+    return j;
+}
+template <int CTRL>
+__device__ __forceinline__ void max_step(double& v, int& code) {
+    const double ov = dpp_d<CTRL>(v); const int oc = dpp_i<CTRL>(code);
+    if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
+}
+
+constexpr int BIGI = 1 << 20;
+
+#ifdef POLISH_PROF
+#define PROF_MARK(i) do { const long long t_ = clock64(); if (lane == 0 && p.prof) atomicAdd(p.prof + (i), (unsigned long long)(t_ - tprof)); tprof = t_; } while (0)
+#define PROF_CNT(i) do { if (lane == 0 && p.prof) atomicAdd(p.prof + (i), 1ull); } while (0)
+#else
+#define PROF_MARK(i)
+#define PROF_CNT(i)
+#endif
+
+// row of the lane's j-th register element: pairs (16 jj + 2 g, +1) -- two adjacent rows per lane so that LDS
+// reads pair up (ds_read2_b64) and global loads/stores are 16 bytes per lane, 128 bytes per instance
+#define ROWJ(j) (16 * ((j) >> 1) + ((j) & 1) + 2 * g)
+#define COLJ(j) (16 * ((j) >> 1) + ((j) & 1))
+#define ROW_OWNER(r) ((((r) >> 1) & 7) == g)
+#define ROW_BIT(r) ((((r) >> 4) << 1) | ((r) & 1))
+
+template <int RP, int KMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int IPW = THREADS / 8;     // instances per workgroup
+    constexpr int NS = KMAX / 8;         // list slots per lane: position a = 8 i + g
+    constexpr int RPL = 2 * RP;          // rows per lane
+    constexpr int NQ = 16 * RP;          // rows incl. padding
+    constexpr int LD = NQ | 1;           // odd row stride: distinct rows of Hi start in distinct banks
+    constexpr int CH = 4, XCH = 2;       // list columns handled per uniform-exit test (loads of a chunk are in flight together)
+    const int n = p.n, nx = p.nx;
+    const int tid = threadIdx.x, g = tid & 7, li = tid >> 3;
+    [[maybe_unused]] const int lane = tid & 63;
+    double* sHi = reinterpret_cast<double*>(smem);   // [n][LD], columns >= n are zero
+    double* sLb = sHi + (size_t)n * LD;              // [NQ] padded rows: -1e300
+    double* sUb = sLb + NQ;                          // [NQ] padded rows: +1e300
+    double* sD = sUb + NQ;                           // [NQ] Jacobi scaling
+    double* sStage = sD + NQ;                        // prologue: KuT, FsT [(nx+1)][NQ], x0 [64][nx]; then the exchange scratch
+    double* sKu = sStage;
+    double* sFs = sKu + (size_t)(nx + 1) * NQ;
+    double* sX0 = sFs + (size_t)(nx + 1) * NQ;
+    double* myR = sStage + (size_t)li * KMAX;                                  // [IPW][KMAX] vector exchange 1
+    double* myV = sStage + (size_t)(IPW + li) * KMAX;                          // [IPW][KMAX] vector exchange 2
+    int* myA = reinterpret_cast<int*>(sStage + (size_t)2 * IPW * KMAX) + li * KMAX; // [IPW][KMAX] row of each list slot
+
+#ifdef POLISH_PROF
+    long long tprof = clock64();
+#endif
+    // instances: a contiguous block of the batch, or (second chance pass) entries of a device-side queue
+    const int total = p.qin ? *p.qin_count : p.B;
+    const int slot0 = blockIdx.x * IPW;
+    if (slot0 >= total) return;
+    const bool valid = slot0 + li < total;
+    const int inst = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
+
+    // ---- stage the shared data --------------------------------------------------------------
+    {   // Hi -> LDS, six rows in flight per thread (n <= 128 columns: one column per thread of a 128-group)
+        constexpr int TR = THREADS / 128;
+        const int tc = tid & 127, tr = tid >> 7;
+        for (int r0 = tr; r0 < n; r0 += 6 * TR) {
+            double v[6];
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; v[u] = (r < n && tc < n) ? p.Hi[(size_t)r * n + tc] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; if (r < n && tc < n) sHi[r * LD + tc] = v[u]; }
+        }
+        const int npad = LD - n;            // zero columns n .. LD-1
+        for (int idx = tid; idx < n * npad; idx += THREADS) { const int r = idx / npad; sHi[r * LD + n + (idx - r * npad)] = 0.0; }
+    }
+    for (int j = tid; j < NQ; j += THREADS) {
+        sLb[j] = (j < n) ? p.lbs[j] : -1e300;
+        sUb[j] = (j < n) ? p.ubs[j] : 1e300;
+        sD[j] = (j < n) ? p.d[j] : 0.0;
+    }
+    for (int idx = tid; idx < (nx + 1) * NQ; idx += THREADS) {
+        const int c = idx / NQ, j = idx - c * NQ;
+        sKu[idx] = (j < n) ? p.KuT[(size_t)c * p.NP + j] : 0.0;
+        sFs[idx] = (j < n) ? p.FsT[(size_t)c * p.NP + j] : 0.0;
+    }
+    for (int idx = tid; idx < IPW * nx; idx += THREADS) {
+        const int l2 = idx / nx, c = idx - l2 * nx;
+        const bool v2 = slot0 + l2 < total;
+        const int i2 = v2 ? (p.qin ? p.qin[slot0 + l2] : slot0 + l2) : 0;
+        sX0[idx] = v2 ? p.x0[(size_t)i2 * nx + c] : 0.0;
+    }
+    __syncthreads();
+    PROF_MARK(0);
+
+    // ---- unconstrained minimiser xu = Ku1 [x0;1] on my rows, and c0 = qs'xu ----------------------
+    double x[RPL];
+    double c0 = 0.0;
+    {
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) x[j] = sKu[nx * NQ + ROWJ(j)];
+        for (int c = 0; c < nx; ++c) {
+            const double xc = sX0[li * nx + c];
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) x[j] += sKu[c * NQ + ROWJ(j)] * xc;
+        }
+        double q[RPL];
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) q[j] = sFs[nx * NQ + ROWJ(j)];
+        for (int c = 0; c < nx; ++c) {
+            const double xc = sX0[li * nx + c];
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) q[j] += sFs[c * NQ + ROWJ(j)] * xc;
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) c0 += q[j] * x[j];
+        c0 = grp_sum(c0);
+    }
+
+    // ---- active-set guess from the ADMM iterate (z at a bound and the scaled dual pushing outwards) ---
+    unsigned mU = 0u, mL = 0u;
+    double* zb = p.z + (size_t)inst * p.NP;
+    double* wb = p.w + (size_t)inst * p.NP;
+    if (valid) {
+        double zz[RPL], ww[RPL];
+        if (!(n & 1)) {     // pairs never straddle n: 16-byte loads
+#pragma unroll
+            for (int jj = 0; jj < RP; ++jj) {
+                const int row = ROWJ(2 * jj);
+                double2 a = make_double2(0.0, 0.0), b = a;
+                if (row < n) { a = *reinterpret_cast<const double2*>(zb + row); b = *reinterpret_cast<const double2*>(wb + row); }
+                zz[2 * jj] = a.x; zz[2 * jj + 1] = a.y; ww[2 * jj] = b.x; ww[2 * jj + 1] = b.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int row = ROWJ(j);
+                zz[j] = (row < n) ? zb[row] : 0.0;
+                ww[j] = (row < n) ? wb[row] : 0.0;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int row = ROWJ(j);
+            const double hi = sUb[row], lo = sLb[row];
+            const double tz = 1e-9 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
+            const double tw = 1e-12 * fmax(1.0, fabs(zz[j]));
+            if (row < n) {
+                if (zz[j] >= hi - tz && ww[j] > tw) mU |= 1u << j;
+                else if (zz[j] <= lo + tz && ww[j] < -tw) mL |= 1u << j;
+            }
+        }
+    }
+    __syncthreads();       // the stage area becomes the exchange scratch
+#pragma unroll
+    for (int i = 0; i < NS; ++i) { myR[8 * i + g] = 0.0; myV[8 * i + g] = 0.0; myA[8 * i + g] = 0; }
+    wsync();
+
+    // ---- per-instance state -------------------------------------------------------------------------
+    double W[NS][KMAX];                 // rows 8i+g of S^-1 (zero where a slot is free)
+    double lam[NS], rhs[NS], sgO[NS];   // my slots: multiplier (signed), xu[row]-bound, side (+1 upper, -1 lower, 0 free)
+    int raO[NS];                        // my slots: row index (0 if free)
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        lam[i] = rhs[i] = sgO[i] = 0.0; raO[i] = 0;
+#pragma unroll
+        for (int c = 0; c < KMAX; ++c) W[i][c] = 0.0;
+    }
+    unsigned live = 0u;                 // occupied slots (same in the 8 lanes)
+    int khi = 0;                        // 1 + highest slot ever occupied
+    bool over = false, fail = false;
+    int steps = 0, why = 0;
+
+    // r = W h with h_c = Hi[p][row_c]; also h at my own slots
+    auto sinv_h = [&](int po, int lim, double (&r)[NS], double (&hown)[NS]) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) r[i] = 0.0;
+#pragma unroll
+        for (int cb = 0; cb < KMAX; cb += CH) {
+            if (!__any(cb < lim)) break;
+            int rw[CH]; double h[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) rw[u] = myA[cb + u];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) h[u] = sHi[po + rw[u]];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) r[i] += W[i][cb + u] * h[u];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) hown[i] = sHi[po + raO[i]];
+    };
+    // W += coef_a * myR[c]
+    auto rank1 = [&](const double (&coef)[NS], int lim) {
+#pragma unroll
+        for (int cb = 0; cb < KMAX; cb += CH) {
+            if (!__any(cb < lim)) break;
+            double uu[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) uu[u] = myR[cb + u];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) W[i][cb + u] += coef[i] * uu[u];
+        }
+    };
+    // remove slot jb (predicate d): W -= W[:,jb] W[jb,:] / W[jb,jb]
+    auto drop = [&](int jb, bool d) {
+        int row = 0;
+        if (d) row = myA[jb];
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+            if (d && 8 * i + g == jb) {
+#pragma unroll
+                for (int c = 0; c < KMAX; ++c) myV[c] = W[i][c];
+            }
+        wsync();
+        const double vjj = d ? myV[jb] : 1.0;
+        const double al = d ? -1.0 / vjj : 0.0;
+        double ai[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) ai[i] = myV[8 * i + g] * al;
+#pragma unroll
+        for (int cb = 0; cb < KMAX; cb += CH) {
+            if (!__any(cb < khi)) break;
+            double vc[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) vc[u] = myV[cb + u];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    W[i][cb + u] += ai[i] * vc[u];
+                    if (d && (cb + u == jb || 8 * i + g == jb)) W[i][cb + u] = 0.0;
+                }
+        }
+        if (d) {
+            live &= ~(1u << jb);
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (8 * i + g == jb) { lam[i] = 0.0; rhs[i] = 0.0; sgO[i] = 0.0; raO[i] = 0; }
+            if (ROW_OWNER(row)) { mU &= ~(1u << ROW_BIT(row)); mL &= ~(1u << ROW_BIT(row)); }
+        }
+        wsync();
+        if (d && (jb & 7) == g) myA[jb] = 0;
+        wsync();
+    };
+
+    PROF_MARK(1);
+    // ---- warm phase ---------------------------------------------------------------------------------
+    {
+        // ordered list of the guessed set: lane g's rows after those of lanes < g
+        const unsigned m = mU | mL;
+        int* cntp = reinterpret_cast<int*>(myR);
+        cntp[g] = __popc(m);
+        wsync();
+        int off = 0, k0 = 0;
+#pragma unroll
+        for (int gg = 0; gg < 8; ++gg) { const int cg = cntp[gg]; if (gg < g) off += cg; k0 += cg; }
+        wsync();
+        if (g < 4) myR[g] = 0.0;     // the 8 counters overlaid myR[0..3]
+        wsync();
+        bool wact = valid;
+        if (wact && k0 > KMAX) { over = true; why = 1; wact = false; }
+        if (wact) {
+#pragma unroll
+            for (int j = 0; j < RPL; ++j)
+                if ((m >> j) & 1u) {
+                    const int row = ROWJ(j);
+                    const bool up = (mU >> j) & 1u;
+                    myA[off] = row;
+                    myR[off] = up ? 1.0 : -1.0;
+                    myV[off] = x[j] - (up ? sUb[row] : sLb[row]);
+                    ++off;
+                }
+        }
+        wsync();
+        if (!wact) k0 = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const int a = 8 * i + g;
+            const bool in = a < k0;
+            raO[i] = in ? myA[a] : 0;
+            sgO[i] = in ? myR[a] : 0.0;
+            rhs[i] = in ? myV[a] : 0.0;
+        }
+        live = k0 >= 32 ? 0xFFFFFFFFu : ((1u << k0) - 1u);
+        khi = k0;
+        wsync();
+        // W = S^-1 by successive bordering in list order
+        for (int t = 0; t < KMAX; ++t) {
+            PROF_CNT(7);
+            const bool actt = wact && t < k0;
+            if (!__any(actt)) break;
+            const int pr = actt ? myA[t] : 0;
+            const int po = pr * LD;
+            double r[NS], hown[NS];
+            sinv_h(po, min(t, k0), r, hown);
+            double part = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) part += hown[i] * r[i];
+            const double d2 = sHi[po + pr] - grp_sum(part);
+            bool go = actt;
+            if (go && !(d2 > 0.0)) { fail = true; why = 2; wact = false; go = false; }
+            const double rd2 = go ? 1.0 / d2 : 0.0;
+            double coef[NS];
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double u = (8 * i + g == t) ? -1.0 : r[i];
+                myR[8 * i + g] = u;
+                coef[i] = u * rd2;
+            }
+            wsync();
+            rank1(coef, min(t + 1, k0));
+            wsync();
+        }
+        if (fail) { live = 0u; }
+        PROF_MARK(2);
+        // multipliers on the guessed set; release the wrong-signed ones and solve again
+        for (;;) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) myV[8 * i + g] = rhs[i];
+            wsync();
+#pragma unroll
+            for (int i = 0; i < NS; ++i) lam[i] = 0.0;
+#pragma unroll
+            for (int cb = 0; cb < KMAX; cb += CH) {
+                if (!__any(cb < khi)) break;
+                double v[CH];
+#pragma unroll
+                for (int u = 0; u < CH; ++u) v[u] = myV[cb + u];
+#pragma unroll
+                for (int u = 0; u < CH; ++u)
+#pragma unroll
+                    for (int i = 0; i < NS; ++i) lam[i] += W[i][cb + u] * v[u];
+            }
+            wsync();
+            bool bad[NS]; bool anyb = false;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { bad[i] = wact && sgO[i] * lam[i] < 0.0; anyb = anyb || bad[i]; }
+            if (!__any(anyb)) break;
+            for (;;) {
+                int cand = BIGI;
+#pragma unroll
+                for (int i = NS - 1; i >= 0; --i) if (bad[i]) cand = 8 * i + g;
+                const int jb = grp_imin(cand);
+                const bool d = jb < BIGI;
+                if (!__any(d)) break;
+                drop(d ? jb : 0, d);
+                if (d) ++steps;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) if (8 * i + g == jb) bad[i] = false;
+            }
+        }
+    }
+
+    PROF_MARK(3);
+    // x -= Hi[:,A] c for the list-ordered coefficients c (my slots in cown)
+    auto x_minus = [&](const double (&cown)[NS]) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) myR[8 * i + g] = cown[i];
+        wsync();
+#pragma unroll
+        for (int cb = 0; cb < KMAX; cb += XCH) {
+            if (!__any(cb < khi)) break;
+            double la[XCH]; int oa[XCH];
+#pragma unroll
+            for (int u = 0; u < XCH; ++u) { la[u] = myR[cb + u]; oa[u] = myA[cb + u] * LD + 2 * g; }
+#pragma unroll
+            for (int u = 0; u < XCH; ++u)
+#pragma unroll
+                for (int j = 0; j < RPL; ++j) x[j] -= sHi[oa[u] + COLJ(j)] * la[u];
+        }
+        wsync();
+    };
+    // e = rhs - S lam on my slots, with S read from Hi itself (not from the updated inverse W)
+    auto resid = [&](double (&e)[NS]) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { myR[8 * i + g] = lam[i]; e[i] = rhs[i]; }
+        wsync();
+        int ro[NS];
+#pragma unroll
+        for (int i = 0; i < NS; ++i) ro[i] = raO[i] * LD;
+#pragma unroll
+        for (int cb = 0; cb < KMAX; cb += CH) {
+            if (!__any(cb < khi)) break;
+            int rw[CH]; double lv[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) { rw[u] = myA[cb + u]; lv[u] = myR[cb + u]; }
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) e[i] -= sHi[ro[i] + rw[u]] * lv[u];
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i) if (sgO[i] == 0.0) e[i] = 0.0;
+        wsync();
+    };
+    // dl = W e
+    auto w_times = [&](const double (&e)[NS], double (&dl)[NS]) {
+#pragma unroll
+        for (int i = 0; i < NS; ++i) { myV[8 * i + g] = e[i]; dl[i] = 0.0; }
+        wsync();
+#pragma unroll
+        for (int cb = 0; cb < KMAX; cb += CH) {
+            if (!__any(cb < khi)) break;
+            double v[CH];
+#pragma unroll
+            for (int u = 0; u < CH; ++u) v[u] = myV[cb + u];
+#pragma unroll
+            for (int u = 0; u < CH; ++u)
+#pragma unroll
+                for (int i = 0; i < NS; ++i) dl[i] += W[i][cb + u] * v[u];
+        }
+        wsync();
+    };
+
+    // one refinement of the multipliers against S itself (W is a product of rank-one updates), then
+    // x = xu - Hi[:,A] lam on every row (rows in A land on their bound up to rounding; they are
+    // reported as the bound itself and never tested for violation)
+    {
+        double e[NS], dl[NS];
+        resid(e);
+        w_times(e, dl);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) lam[i] += dl[i];
+        x_minus(lam);
+    }
+
+    PROF_MARK(4);
+    // ---- main phase: add the most violated bound until none is violated ----------------------------
+    bool run = valid && !over && !fail;
+    int guard = 0;
+    for (;;) {
+        double best = 0.0; int code = -1;
+        const unsigned m = mU | mL;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int row = ROWJ(j);
+            const double hi = sUb[row], lo = sLb[row];
+            const double tol = 1e-12 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
+            const double vu = x[j] - hi, vl = lo - x[j];
+            const double v = fmax(vu, vl);
+            if (!((m >> j) & 1u) && v > tol && v > best) { best = v; code = 2 * row + (vu > vl ? 1 : 0); }
+        }
+        max_step<DPP_XOR1>(best, code); max_step<DPP_XOR2>(best, code); max_step<DPP_HMIRROR>(best, code);
+        bool has = run && code >= 0;
+        if (!__any(has)) break;
+        if (has && ++guard > p.max_steps) { fail = true; why = 5; run = false; has = false; }
+        const int pr = has ? (code >> 1) : 0;
+        const int po = pr * LD;
+        const bool upP = code & 1;
+        const double sp = upP ? 1.0 : -1.0;
+        const double hpp = sHi[po + pr];
+        double viol = best, rp = 0.0, accl = 0.0;
+        bool first = true;
+        bool inner = has;
+        while (__any(inner)) {
+            PROF_CNT(8);
+            double r[NS], hown[NS];
+            sinv_h(po, khi, r, hown);
+            double part = 0.0, part2 = 0.0;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { part += hown[i] * r[i]; part2 += hown[i] * lam[i]; }
+            const double d2 = hpp - grp_sum(part);
+            if (first) { rp = sp * viol + grp_sum(part2); first = false; }   // xu_p - bnd_p = (x_p - bnd_p) + (Hi lam)_p
+            if (inner && !(d2 > 0.0)) { fail = true; why = 4; run = false; inner = false; }
+            const double rd2 = 1.0 / d2;
+            const double t2 = viol * rd2;
+            double t1 = 1e300; int jb = BIGI;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const double rr = sp * r[i];
+                if (sgO[i] * rr > 0.0) {
+                    const double t = lam[i] / rr;
+                    if (t < t1) { t1 = t; jb = 8 * i + g; }
+                }
+            }
+            grp_min(t1, jb);
+            const bool full = (t2 <= t1);
+            const double t = inner ? (full ? t2 : t1) : 0.0;
+            // x -= t (sp Hi[:,p] - Hi[:,A] (sp r)),  lam_A -= t sp r
+#pragma unroll
+            for (int i = 0; i < NS; ++i) myR[8 * i + g] = r[i];
+            wsync();
+            const double cp = t * sp;
+            {
+                const int op = po + 2 * g;
+#pragma unroll
+                for (int j = 0; j < RPL; ++j) x[j] -= cp * sHi[op + COLJ(j)];
+            }
+#pragma unroll
+            for (int cb = 0; cb < KMAX; cb += XCH) {
+                if (!__any(cb < khi)) break;
+                double ca[XCH]; int oa[XCH];
+#pragma unroll
+                for (int u = 0; u < XCH; ++u) { ca[u] = cp * myR[cb + u]; oa[u] = myA[cb + u] * LD + 2 * g; }
+#pragma unroll
+                for (int u = 0; u < XCH; ++u)
+#pragma unroll
+                    for (int j = 0; j < RPL; ++j) x[j] += ca[u] * sHi[oa[u] + COLJ(j)];
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i) lam[i] -= cp * r[i];
+            accl += cp;
+            if (inner) ++steps;
+            bool app = inner && full, drp = inner && !full;
+            int pos = 0;
+            if (app) {
+                pos = __ffs(~live) - 1;
+                if (pos < 0 || pos >= KMAX) { over = true; why = 3; run = false; app = false; pos = 0; }
+                inner = false;
+            }
+            if (__any(app)) {
+                wsync();
+                if (app && (pos & 7) == g) { myR[pos] = -1.0; myA[pos] = pr; }
+                if (app) khi = max(khi, pos + 1);
+                wsync();
+                double coef[NS];
+#pragma unroll
+                for (int i = 0; i < NS; ++i) coef[i] = app ? ((8 * i + g == pos) ? -rd2 : r[i] * rd2) : 0.0;
+                rank1(coef, khi);
+                if (app) {
+#pragma unroll
+                    for (int i = 0; i < NS; ++i)
+                        if (8 * i + g == pos) { lam[i] = accl; rhs[i] = rp; raO[i] = pr; sgO[i] = sp; }
+                    live |= 1u << pos;
+                    if (ROW_OWNER(pr)) { if (upP) mU |= 1u << ROW_BIT(pr); else mL |= 1u << ROW_BIT(pr); }
+                }
+            }
+            if (__any(drp)) {
+                if (drp) viol -= t * d2;
+                drop(drp ? jb : 0, drp);
+                if (drp && ++guard > p.max_steps) { fail = true; why = 6; run = false; inner = false; }
+            }
+            wsync();
+        }
+    }
+
+    // ---- refinement: the active rows of x must sit ON their bounds, i.e. S lam = rhs with the true S -----
+    for (int itr = 0; itr < 3; ++itr) {
+        double e[NS], dl[NS];
+        resid(e);
+        bool need = false;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) need = need || fabs(e[i]) > 1e-13 * fmax(1.0, fabs(rhs[i]));
+        if (!__any(need && run)) break;
+        w_times(e, dl);
+#pragma unroll
+        for (int i = 0; i < NS; ++i) lam[i] += dl[i];
+        x_minus(dl);
+    }
+
+    PROF_MARK(5);
+    // ---- outputs --------------------------------------------------------------------------------------
+    const bool okk = valid && !over && !fail;
+    if (valid && g == 0) {
+        p.need_big[inst] = okk ? 0 : (why ? why : 7);
+        if (!okk && p.qout) p.qout[atomicAdd(p.qout_count, 1)] = inst;      // queue for the next, larger pass
+    }
+    double dual = 0.0;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) dual += lam[i] * rhs[i];
+    dual = grp_sum(dual);
+    const double obj = 0.5 * c0 + 0.5 * dual;       // f(xu) + 1/2 lam'S lam
+#ifdef POLISH_NOOUT
+    if (okk && p.B < 0) {
+#else
+    if (okk) {
+#endif
+        if (!(n & 1)) {     // 16-byte stores; a pair holding an active row writes its multipliers one by one
+#pragma unroll
+            for (int jj = 0; jj < RP; ++jj) {
+                const int row = ROWJ(2 * jj);
+                if (row < n) {
+                    const unsigned a2 = ((mU | mL) >> (2 * jj)) & 3u;
+                    double2 xo;
+                    xo.x = ((mU >> (2 * jj)) & 1u) ? sUb[row] : (((mL >> (2 * jj)) & 1u) ? sLb[row] : x[2 * jj]);
+                    xo.y = ((mU >> (2 * jj + 1)) & 1u) ? sUb[row + 1] : (((mL >> (2 * jj + 1)) & 1u) ? sLb[row + 1] : x[2 * jj + 1]);
+                    *reinterpret_cast<double2*>(p.U + (size_t)inst * n + row) = make_double2(sD[row] * xo.x, sD[row + 1] * xo.y);
+                    *reinterpret_cast<double2*>(zb + row) = xo;          // the polished point is the warm-start state
+                    if (a2 == 0u) {
+                        *reinterpret_cast<double2*>(wb + row) = make_double2(0.0, 0.0);
+                        if (p.info.lam) *reinterpret_cast<double2*>(p.info.lam + (size_t)inst * n + row) = make_double2(0.0, 0.0);
+                    } else {
+                        if (!(a2 & 1u)) { wb[row] = 0.0; if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0; }
+                        if (!(a2 & 2u)) { wb[row + 1] = 0.0; if (p.info.lam) p.info.lam[(size_t)inst * n + row + 1] = 0.0; }
+                    }
+                }
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int row = ROWJ(j);
+                if (row < n) {
+                    const bool act = ((mU | mL) >> j) & 1u;
+                    const double xo = ((mU >> j) & 1u) ? sUb[row] : (((mL >> j) & 1u) ? sLb[row] : x[j]);
+                    p.U[(size_t)inst * n + row] = sD[row] * xo;
+                    zb[row] = xo;
+                    if (!act) {                 // rows in the active set get their multiplier from the slot owner below
+                        wb[row] = 0.0;
+                        if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0;
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NS; ++i)
+            if (sgO[i] != 0.0) {
+                const int row = raO[i];
+                wb[row] = lam[i] / p.rho;
+                if (p.info.lam) p.info.lam[(size_t)inst * n + row] = lam[i] / sD[row];
+            }
+        if (g == 0) {
+            if (p.info.status) p.info.status[inst] = MPCQP_SOLVED;
+            if (p.info.obj) p.info.obj[inst] = obj;
+            if (p.info.iters) p.info.iters[inst] = p.it_ws[inst];
+            if (p.info.prim_res) p.info.prim_res[inst] = p.rp_ws[inst];
+            if (p.info.dual_res) p.info.dual_res[inst] = p.rd_ws[inst];
+            if (p.info.polish_steps) p.info.polish_steps[inst] = steps;
+        }
+    }
+    PROF_MARK(6);
+}
+
+template <int RP, int KMAX, int THREADS>
+int launch_oct(const PolParams& p, int ninst, hipStream_t st) {
+    constexpr int NQ = 16 * RP, LD = NQ | 1, IPW = THREADS / 8;
+    const size_t stage = (size_t)(2 * (p.nx + 1) * NQ + IPW * p.nx) * 8;
+    const size_t xch = (size_t)IPW * KMAX * 20;
+    const size_t lds = ((size_t)p.n * LD + 3 * NQ) * 8 + (stage > xch ? stage : xch);
+    if (lds > 160 * 1024) return -1;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_oct_kernel<RP, KMAX, THREADS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((polish_oct_kernel<RP, KMAX, THREADS>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
+    return (int)hipGetLastError();
+}
+
+template <int KMAX, int THREADS>
+int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
+    const int rp = ceil_div(p.n, 16);
+    if (rp <= 2) return launch_oct<2, KMAX, THREADS>(p, ninst, st);
+    if (rp <= 4) return launch_oct<4, KMAX, THREADS>(p, ninst, st);
+    if (rp <= 6) return launch_oct<6, KMAX, THREADS>(p, ninst, st);
+    if (rp <= 8) return launch_oct<8, KMAX, THREADS>(p, ninst, st);
+    return -1;
+}
+
+}  // namespace
+
+// Fast polish: pass A takes the whole batch with KMAX = 16 (two waves per SIMD); what outgrows it is queued
+// on the device and retried by pass B with KMAX = 32 (one wave per SIMD, 512 registers) on at most
+// `second_cap` queue slots; what is left after that is queued in p2.qout for the wave-per-instance kernel.
+// returns 0 on launch, -1 if the shape does not fit this path, a hipError_t (> 0) otherwise
+int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st) {
+    if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
+    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    PolParams a = p;
+    a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
+    int rc = launch_oct_rp<16, 512>(a, p.B, st);
+    if (rc != 0) return rc;
+    PolParams b = p;
+    b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
+    return launch_oct_rp<32, 256>(b, p.B, st);
+}
