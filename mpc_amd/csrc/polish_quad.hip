@@ -42,11 +42,14 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
-// sum over the 8 lanes of a group, result in all of them
+constexpr int DPP_ROR8 = 0x128;                     // row_ror:8: lane i <-> i+8 of each 16
+// sum over the G (8 or 16) lanes of a group, result in all of them
+template <int G>
 __device__ __forceinline__ double grp_sum(double v) {
     v += dpp_d<DPP_XOR1>(v);
     v += dpp_d<DPP_XOR2>(v);
     v += dpp_d<DPP_HMIRROR>(v);
+    if (G == 16) v += dpp_d<DPP_ROR8>(v);
     return v;
 }
 template <int CTRL>
@@ -55,19 +58,28 @@ __device__ __forceinline__ void min_step(double& t, int& j) {
     if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
 }
 // (smallest t, its index; ties to the lower index) over the group
+template <int G>
 __device__ __forceinline__ void grp_min(double& t, int& j) {
     min_step<DPP_XOR1>(t, j); min_step<DPP_XOR2>(t, j); min_step<DPP_HMIRROR>(t, j);
+    if (G == 16) min_step<DPP_ROR8>(t, j);
 }
 template <int CTRL>
 __device__ __forceinline__ void imin_step(int& j) { const int oj = dpp_i<CTRL>(j); j = oj < j ? oj : j; }
+template <int G>
 __device__ __forceinline__ int grp_imin(int j) {
     imin_step<DPP_XOR1>(j); imin_step<DPP_XOR2>(j); imin_step<DPP_HMIRROR>(j);
+    if (G == 16) imin_step<DPP_ROR8>(j);
     return j;
 }
 template <int CTRL>
 __device__ __forceinline__ void max_step(double& v, int& code) {
     const double ov = dpp_d<CTRL>(v); const int oc = dpp_i<CTRL>(code);
     if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
+}
+template <int G>
+__device__ __forceinline__ void grp_max(double& v, int& code) {
+    max_step<DPP_XOR1>(v, code); max_step<DPP_XOR2>(v, code); max_step<DPP_HMIRROR>(v, code);
+    if (G == 16) max_step<DPP_ROR8>(v, code);
 }
 
 constexpr int BIGI = 1 << 20;
@@ -82,22 +94,22 @@ constexpr int BIGI = 1 << 20;
 
 // row of the lane's j-th register element: pairs (16 jj + 2 g, +1) -- two adjacent rows per lane so that LDS
 // reads pair up (ds_read2_b64) and global loads/stores are 16 bytes per lane, 128 bytes per instance
-#define ROWJ(j) (16 * ((j) >> 1) + ((j) & 1) + 2 * g)
-#define COLJ(j) (16 * ((j) >> 1) + ((j) & 1))
-#define ROW_OWNER(r) ((((r) >> 1) & 7) == g)
-#define ROW_BIT(r) ((((r) >> 4) << 1) | ((r) & 1))
+#define ROWJ(j) (2 * G * ((j) >> 1) + ((j) & 1) + 2 * g)
+#define COLJ(j) (2 * G * ((j) >> 1) + ((j) & 1))
+#define ROW_OWNER(r) ((((r) >> 1) & (G - 1)) == g)
+#define ROW_BIT(r) ((((r) / (2 * G)) << 1) | ((r) & 1))
 
-template <int RP, int KMAX, int THREADS>
+template <int G, int RP, int KMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int IPW = THREADS / 8;     // instances per workgroup
-    constexpr int NS = KMAX / 8;         // list slots per lane: position a = 8 i + g
+    constexpr int IPW = THREADS / G;     // instances per workgroup
+    constexpr int NS = KMAX / G;         // list slots per lane: position a = G i + g
     constexpr int RPL = 2 * RP;          // rows per lane
-    constexpr int NQ = 16 * RP;          // rows incl. padding
+    constexpr int NQ = 2 * G * RP;       // rows incl. padding
     constexpr int LD = NQ | 1;           // odd row stride: distinct rows of Hi start in distinct banks
     constexpr int CH = 4, XCH = 2;       // list columns handled per uniform-exit test (loads of a chunk are in flight together)
     const int n = p.n, nx = p.nx;
-    const int tid = threadIdx.x, g = tid & 7, li = tid >> 3;
+    const int tid = threadIdx.x, g = tid & (G - 1), li = tid / G;
     [[maybe_unused]] const int lane = tid & 63;
     double* sHi = reinterpret_cast<double*>(smem);   // [n][LD], columns >= n are zero
     double* sLb = sHi + (size_t)n * LD;              // [NQ] padded rows: -1e300
@@ -175,7 +187,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         }
 #pragma unroll
         for (int j = 0; j < RPL; ++j) c0 += q[j] * x[j];
-        c0 = grp_sum(c0);
+        c0 = grp_sum<G>(c0);
     }
 
     // ---- active-set guess from the ADMM iterate (z at a bound and the scaled dual pushing outwards) ---
@@ -214,7 +226,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     }
     __syncthreads();       // the stage area becomes the exchange scratch
 #pragma unroll
-    for (int i = 0; i < NS; ++i) { myR[8 * i + g] = 0.0; myV[8 * i + g] = 0.0; myA[8 * i + g] = 0; }
+    for (int i = 0; i < NS; ++i) { myR[G * i + g] = 0.0; myV[G * i + g] = 0.0; myA[G * i + g] = 0; }
     wsync();
 
     // ---- per-instance state -------------------------------------------------------------------------
@@ -272,7 +284,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         if (d) row = myA[jb];
 #pragma unroll
         for (int i = 0; i < NS; ++i)
-            if (d && 8 * i + g == jb) {
+            if (d && G * i + g == jb) {
 #pragma unroll
                 for (int c = 0; c < KMAX; ++c) myV[c] = W[i][c];
             }
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         const double al = d ? -1.0 / vjj : 0.0;
         double ai[NS];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) ai[i] = myV[8 * i + g] * al;
+        for (int i = 0; i < NS; ++i) ai[i] = myV[G * i + g] * al;
 #pragma unroll
         for (int cb = 0; cb < KMAX; cb += CH) {
             if (!__any(cb < khi)) break;
@@ -293,18 +305,18 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     W[i][cb + u] += ai[i] * vc[u];
-                    if (d && (cb + u == jb || 8 * i + g == jb)) W[i][cb + u] = 0.0;
+                    if (d && (cb + u == jb || G * i + g == jb)) W[i][cb + u] = 0.0;
                 }
         }
         if (d) {
             live &= ~(1u << jb);
 #pragma unroll
             for (int i = 0; i < NS; ++i)
-                if (8 * i + g == jb) { lam[i] = 0.0; rhs[i] = 0.0; sgO[i] = 0.0; raO[i] = 0; }
+                if (G * i + g == jb) { lam[i] = 0.0; rhs[i] = 0.0; sgO[i] = 0.0; raO[i] = 0; }
             if (ROW_OWNER(row)) { mU &= ~(1u << ROW_BIT(row)); mL &= ~(1u << ROW_BIT(row)); }
         }
         wsync();
-        if (d && (jb & 7) == g) myA[jb] = 0;
+        if (d && (jb & (G - 1)) == g) myA[jb] = 0;
         wsync();
     };
 
@@ -318,9 +330,9 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         wsync();
         int off = 0, k0 = 0;
 #pragma unroll
-        for (int gg = 0; gg < 8; ++gg) { const int cg = cntp[gg]; if (gg < g) off += cg; k0 += cg; }
+        for (int gg = 0; gg < G; ++gg) { const int cg = cntp[gg]; if (gg < g) off += cg; k0 += cg; }
         wsync();
-        if (g < 4) myR[g] = 0.0;     // the 8 counters overlaid myR[0..3]
+        if (g < G / 2) myR[g] = 0.0;     // the G counters overlaid myR[0..G/2)
         wsync();
         bool wact = valid;
         if (wact && k0 > KMAX) { over = true; why = 1; wact = false; }
@@ -340,7 +352,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         if (!wact) k0 = 0;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const int a = 8 * i + g;
+            const int a = G * i + g;
             const bool in = a < k0;
             raO[i] = in ? myA[a] : 0;
             sgO[i] = in ? myR[a] : 0.0;
@@ -361,15 +373,15 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
             double part = 0.0;
 #pragma unroll
             for (int i = 0; i < NS; ++i) part += hown[i] * r[i];
-            const double d2 = sHi[po + pr] - grp_sum(part);
+            const double d2 = sHi[po + pr] - grp_sum<G>(part);
             bool go = actt;
             if (go && !(d2 > 0.0)) { fail = true; why = 2; wact = false; go = false; }
             const double rd2 = go ? 1.0 / d2 : 0.0;
             double coef[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
-                const double u = (8 * i + g == t) ? -1.0 : r[i];
-                myR[8 * i + g] = u;
+                const double u = (G * i + g == t) ? -1.0 : r[i];
+                myR[G * i + g] = u;
                 coef[i] = u * rd2;
             }
             wsync();
@@ -381,7 +393,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         // multipliers on the guessed set; release the wrong-signed ones and solve again
         for (;;) {
 #pragma unroll
-            for (int i = 0; i < NS; ++i) myV[8 * i + g] = rhs[i];
+            for (int i = 0; i < NS; ++i) myV[G * i + g] = rhs[i];
             wsync();
 #pragma unroll
             for (int i = 0; i < NS; ++i) lam[i] = 0.0;
@@ -404,14 +416,14 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
             for (;;) {
                 int cand = BIGI;
 #pragma unroll
-                for (int i = NS - 1; i >= 0; --i) if (bad[i]) cand = 8 * i + g;
-                const int jb = grp_imin(cand);
+                for (int i = NS - 1; i >= 0; --i) if (bad[i]) cand = G * i + g;
+                const int jb = grp_imin<G>(cand);
                 const bool d = jb < BIGI;
                 if (!__any(d)) break;
                 drop(d ? jb : 0, d);
                 if (d) ++steps;
 #pragma unroll
-                for (int i = 0; i < NS; ++i) if (8 * i + g == jb) bad[i] = false;
+                for (int i = 0; i < NS; ++i) if (G * i + g == jb) bad[i] = false;
             }
         }
     }
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     // x -= Hi[:,A] c for the list-ordered coefficients c (my slots in cown)
     auto x_minus = [&](const double (&cown)[NS]) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) myR[8 * i + g] = cown[i];
+        for (int i = 0; i < NS; ++i) myR[G * i + g] = cown[i];
         wsync();
 #pragma unroll
         for (int cb = 0; cb < KMAX; cb += XCH) {
@@ -438,7 +450,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     // e = rhs - S lam on my slots, with S read from Hi itself (not from the updated inverse W)
     auto resid = [&](double (&e)[NS]) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) { myR[8 * i + g] = lam[i]; e[i] = rhs[i]; }
+        for (int i = 0; i < NS; ++i) { myR[G * i + g] = lam[i]; e[i] = rhs[i]; }
         wsync();
         int ro[NS];
 #pragma unroll
@@ -461,7 +473,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     // dl = W e
     auto w_times = [&](const double (&e)[NS], double (&dl)[NS]) {
 #pragma unroll
-        for (int i = 0; i < NS; ++i) { myV[8 * i + g] = e[i]; dl[i] = 0.0; }
+        for (int i = 0; i < NS; ++i) { myV[G * i + g] = e[i]; dl[i] = 0.0; }
         wsync();
 #pragma unroll
         for (int cb = 0; cb < KMAX; cb += CH) {
@@ -505,7 +517,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
             const double v = fmax(vu, vl);
             if (!((m >> j) & 1u) && v > tol && v > best) { best = v; code = 2 * row + (vu > vl ? 1 : 0); }
         }
-        max_step<DPP_XOR1>(best, code); max_step<DPP_XOR2>(best, code); max_step<DPP_HMIRROR>(best, code);
+        grp_max<G>(best, code);
         bool has = run && code >= 0;
         if (!__any(has)) break;
         if (has && ++guard > p.max_steps) { fail = true; why = 5; run = false; has = false; }
@@ -524,8 +536,8 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
             double part = 0.0, part2 = 0.0;
 #pragma unroll
             for (int i = 0; i < NS; ++i) { part += hown[i] * r[i]; part2 += hown[i] * lam[i]; }
-            const double d2 = hpp - grp_sum(part);
-            if (first) { rp = sp * viol + grp_sum(part2); first = false; }   // xu_p - bnd_p = (x_p - bnd_p) + (Hi lam)_p
+            const double d2 = hpp - grp_sum<G>(part);
+            if (first) { rp = sp * viol + grp_sum<G>(part2); first = false; }   // xu_p - bnd_p = (x_p - bnd_p) + (Hi lam)_p
             if (inner && !(d2 > 0.0)) { fail = true; why = 4; run = false; inner = false; }
             const double rd2 = 1.0 / d2;
             const double t2 = viol * rd2;
@@ -535,15 +547,15 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
                 const double rr = sp * r[i];
                 if (sgO[i] * rr > 0.0) {
                     const double t = lam[i] / rr;
-                    if (t < t1) { t1 = t; jb = 8 * i + g; }
+                    if (t < t1) { t1 = t; jb = G * i + g; }
                 }
             }
-            grp_min(t1, jb);
+            grp_min<G>(t1, jb);
             const bool full = (t2 <= t1);
             const double t = inner ? (full ? t2 : t1) : 0.0;
             // x -= t (sp Hi[:,p] - Hi[:,A] (sp r)),  lam_A -= t sp r
 #pragma unroll
-            for (int i = 0; i < NS; ++i) myR[8 * i + g] = r[i];
+            for (int i = 0; i < NS; ++i) myR[G * i + g] = r[i];
             wsync();
             const double cp = t * sp;
             {
@@ -575,17 +587,17 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
             }
             if (__any(app)) {
                 wsync();
-                if (app && (pos & 7) == g) { myR[pos] = -1.0; myA[pos] = pr; }
+                if (app && (pos & (G - 1)) == g) { myR[pos] = -1.0; myA[pos] = pr; }
                 if (app) khi = max(khi, pos + 1);
                 wsync();
                 double coef[NS];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) coef[i] = app ? ((8 * i + g == pos) ? -rd2 : r[i] * rd2) : 0.0;
+                for (int i = 0; i < NS; ++i) coef[i] = app ? ((G * i + g == pos) ? -rd2 : r[i] * rd2) : 0.0;
                 rank1(coef, khi);
                 if (app) {
 #pragma unroll
                     for (int i = 0; i < NS; ++i)
-                        if (8 * i + g == pos) { lam[i] = accl; rhs[i] = rp; raO[i] = pr; sgO[i] = sp; }
+                        if (G * i + g == pos) { lam[i] = accl; rhs[i] = rp; raO[i] = pr; sgO[i] = sp; }
                     live |= 1u << pos;
                     if (ROW_OWNER(pr)) { if (upP) mU |= 1u << ROW_BIT(pr); else mL |= 1u << ROW_BIT(pr); }
                 }
@@ -623,7 +635,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     double dual = 0.0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) dual += lam[i] * rhs[i];
-    dual = grp_sum(dual);
+    dual = grp_sum<G>(dual);
     const double obj = 0.5 * c0 + 0.5 * dual;       // f(xu) + 1/2 lam'S lam
 #ifdef POLISH_NOOUT
     if (okk && p.B < 0) {
@@ -685,34 +697,38 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     PROF_MARK(6);
 }
 
-template <int RP, int KMAX, int THREADS>
+template <int G, int RP, int KMAX, int THREADS>
 int launch_oct(const PolParams& p, int ninst, hipStream_t st) {
-    constexpr int NQ = 16 * RP, LD = NQ | 1, IPW = THREADS / 8;
+    constexpr int NQ = 2 * G * RP, LD = NQ | 1, IPW = THREADS / G;
     const size_t stage = (size_t)(2 * (p.nx + 1) * NQ + IPW * p.nx) * 8;
     const size_t xch = (size_t)IPW * KMAX * 20;
     const size_t lds = ((size_t)p.n * LD + 3 * NQ) * 8 + (stage > xch ? stage : xch);
     if (lds > 160 * 1024) return -1;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_oct_kernel<RP, KMAX, THREADS>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((polish_oct_kernel<RP, KMAX, THREADS>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
+    hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
     return (int)hipGetLastError();
 }
 
-template <int KMAX, int THREADS>
+// row pairs per lane: n <= 2 G RP
+template <int G, int KMAX, int THREADS>
 int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
-    const int rp = ceil_div(p.n, 16);
-    if (rp <= 2) return launch_oct<2, KMAX, THREADS>(p, ninst, st);
-    if (rp <= 4) return launch_oct<4, KMAX, THREADS>(p, ninst, st);
-    if (rp <= 6) return launch_oct<6, KMAX, THREADS>(p, ninst, st);
-    if (rp <= 8) return launch_oct<8, KMAX, THREADS>(p, ninst, st);
+    const int rp = ceil_div(p.n, 2 * G);
+    if (rp <= 1) return launch_oct<G, 1, KMAX, THREADS>(p, ninst, st);
+    if (rp <= 2) return launch_oct<G, 2, KMAX, THREADS>(p, ninst, st);
+    if (rp <= 4) return launch_oct<G, 4, KMAX, THREADS>(p, ninst, st);
+    if constexpr (G == 8) {
+        if (rp <= 6) return launch_oct<G, 6, KMAX, THREADS>(p, ninst, st);
+        if (rp <= 8) return launch_oct<G, 8, KMAX, THREADS>(p, ninst, st);
+    }
     return -1;
 }
 
 }  // namespace
 
 // Fast polish: pass A takes the whole batch with KMAX = 16 (two waves per SIMD); what outgrows it is queued
-// on the device and retried by pass B with KMAX = 32 (one wave per SIMD, 512 registers) on at most
+// on the device and retried by pass B with KMAX = 32 and sixteen lanes per instance on at most
 // `second_cap` queue slots; what is left after that is queued in p2.qout for the wave-per-instance kernel.
 // returns 0 on launch, -1 if the shape does not fit this path, a hipError_t (> 0) otherwise
 int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st) {
@@ -721,9 +737,9 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (e != hipSuccess) return (int)e;
     PolParams a = p;
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
-    int rc = launch_oct_rp<16, 512>(a, p.B, st);
+    int rc = launch_oct_rp<8, 16, 512>(a, p.B, st);
     if (rc != 0) return rc;
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
-    return launch_oct_rp<32, 256>(b, p.B, st);
+    return launch_oct_rp<16, 32, 256>(b, p.B, st);
 }
