@@ -31,6 +31,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0
+ADMM_TRAFFIC_BYTES_65536 = (2 * 48193.74 + 212947.86) * 1024.0   # profiles/r01_v4_pmc.csv
 
 
 def cpu_baseline(prob, seconds=15.0):
@@ -173,7 +174,7 @@ def main():
             "config": {"workload": "configs[2]: quadrotor hover MPC nx=12 nu=4 N=30 (n=120 box-constrained QP), "
                                    f"{B} random x0 per GPU, shared LTI model",
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world} (independent shards)",
-                       "algorithm": "ADMM (shared (Hs+rho I)^-1, fp64 MFMA) + dual active-set polish",
+                       "algorithm": "ADMM (shared (Hs+rho I)^-1, fp64 MFMA GEMM form) + dual active-set polish (8/16 lanes per instance, Hs^-1 in LDS)",
                        "admm_iters_mean": iters_mean, "admm_iters_max": iters_max,
                        "polish_steps_mean": psteps_mean, "polish_steps_max": psteps_max,
                        "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": setup_ms,
@@ -183,7 +184,12 @@ def main():
                        "hbm_GBps_compulsory": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS},
             "roofline": {"bound": "mfma", "kernel": "admm_shared_box_kernel<8,30>", "achieved": achieved_tf,
                          "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                         "traffic": None,
+                         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
+                         # FETCH_SIZE and WRITE_SIZE in separate runs; FETCH doubled as the gfx950 guide prescribes),
+                         # measured at 65,536 instances and scaled with the batch; not re-measured by this script
+                         "traffic": ADMM_TRAFFIC_BYTES_65536 * B / 65536.0,
+                         "traffic_source": "profiles/r01_v4_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of admm_shared_box_kernel)",
+                         "algorithmic_bytes": B * (8 * prob["nx"] + 3 * 8 * 16 * ((n + 15) // 16)),
                          "flops_per_launch": admm_flops, "launch_ms": admm_ms},
         }
         if world == 1 and not args.no_cpu_baseline:

@@ -65,7 +65,7 @@ typedef struct mpcqp_factor_opts {
 } mpcqp_factor_opts;
 
 typedef struct mpcqp_solve_opts {
-    int    max_iter;      /* ADMM iteration cap                                   (default 10)  */
+    int    max_iter;      /* ADMM iteration cap                                   (default 5)   */
     int    min_iter;      /* iterations before the first convergence check        (default 5)   */
     int    check_every;   /* residual / active-set check period                   (default 5)   */
     double eps_abs;       /* OSQP-style absolute tolerance on scaled residuals    (default 1e-6)*/

@@ -68,7 +68,7 @@ const char* mpcqp_last_error(mpcqp_handle h) { return h ? h->err.c_str() : g_cre
 
 void mpcqp_default_solve_opts(mpcqp_solve_opts* o) {
     if (!o) return;
-    o->max_iter = 10; o->min_iter = 5; o->check_every = 5;
+    o->max_iter = 5; o->min_iter = 5; o->check_every = 5;
     o->eps_abs = 1e-6; o->eps_rel = 1e-6; o->alpha = 1.6;
     o->polish = 1; o->polish_refine = -1; o->polish_max_steps = 0; o->warm_start = 0; o->stages = 3;
 }
