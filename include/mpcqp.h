@@ -108,6 +108,13 @@ int mpcqp_set_cost(mpcqp_handle h, const double* Q, const double* R, const doubl
 /* u_min, u_max: (nu) applied at every stage (per_stage = 0) or (N, nu) (per_stage = 1). */
 int mpcqp_set_constraints(mpcqp_handle h, const double* u_min, const double* u_max, int per_stage);
 
+/* One model per instance (dims.n_models = batch > 1; e.g. an LTV re-linearisation about each instance's own
+ * trajectory): x_ref, u_ref and the bounds may then differ per model too.  Strides are in doubles between
+ * consecutive models, 0 = shared by all (the default).  In this regime there is no shared factor, so
+ * mpcqp_solve skips the ADMM GEMM kernel and the dual active-set kernel does the whole solve (cold, or from the
+ * kept state with warm_start = 1); batch must equal n_models. */
+int mpcqp_set_strides(mpcqp_handle h, long xref_stride, long uref_stride, long bound_stride);
+
 /* -- kernels ----------------------------------------------------------------------- */
 /* rollout Gamma/Phi, H = Gamma'Qbar Gamma + Rbar, F = Gamma'Qbar Phi, f0  (fp64 MFMA) */
 int mpcqp_assemble(mpcqp_handle h, void* stream);
@@ -118,6 +125,11 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U,
                 const mpcqp_info* info, const mpcqp_solve_opts* opts, void* stream);
 /* receding horizon: shift the kept (z, w) one stage forward, repeating the last stage */
 int mpcqp_shift(mpcqp_handle h, void* stream);
+
+/* deviation-form re-linearisation (the reference's `D = D + optX` / `f += delf` pattern, CollocationBasedPlanner2D.py:363,
+ * SE3Planner.py:194-195): when the next QP is posed in increments about the shifted previous plan, the kept primal
+ * state is zeroed (the plan itself is the new origin) while the kept multipliers still mark the active bounds */
+int mpcqp_recenter(mpcqp_handle h, void* stream);
 
 /* -- introspection (device -> caller's device buffers; for tests and parity reports) --- */
 /* which: 0 H (n,n)  1 F (n,nx)  2 f0 (n)  3 Gamma (N nx, n)  4 Phi (N nx, nx)

@@ -45,11 +45,13 @@ SYMBOLS = [
     ("mpcqp_set_model", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     ("mpcqp_set_cost", C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     ("mpcqp_set_constraints", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    ("mpcqp_set_strides", C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_long]),
     ("mpcqp_assemble", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_factor", C.c_int, [C.c_void_p, C.POINTER(FactorOpts), C.c_void_p]),
     ("mpcqp_solve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Info),
                               C.POINTER(SolveOpts), C.c_void_p]),
     ("mpcqp_shift", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mpcqp_recenter", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_get", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),
     ("mpcqp_solve_dense", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 14 + [C.c_void_p]),

@@ -83,9 +83,20 @@ def quadrotor(batch=65536, seed=0, N=30, dt=0.05):
                 u_min=np.array([-5.0, -0.1, -0.1, -0.1]), u_max=np.array([5.0, 0.1, 0.1, 0.1]), x0=x0)
 
 
+def bicycle(batch=8192, seed=0, N=20, dt=0.05):
+    """Config 4: kinematic bicycle (x, y, psi, v; a, delta), L = 2.7 m, lane keeping at 5 m/s; the model is
+    nonlinear, so there is no (A, B) here -- mpc_amd.ltv re-linearises it per instance and per step."""
+    rng = np.random.default_rng(seed)
+    x0 = np.stack((np.zeros(batch), rng.uniform(-2.0, 2.0, batch), rng.uniform(-0.3, 0.3, batch),
+                   rng.uniform(3.0, 7.0, batch)), axis=1)
+    return dict(name="bicycle", nx=4, nu=2, N=N, dt=dt, L=2.7, Q=np.diag([0.0, 1.0, 2.0, 0.5]), R=np.diag([0.1, 5.0]),
+                P=np.diag([0.0, 5.0, 10.0, 2.5]), u_min=np.array([-3.0, -0.5]), u_max=np.array([3.0, 0.5]),
+                v_ref=5.0, x0=x0)
+
+
 def make_config(cfg, batch=None, seed=0):
     """BASELINE.json configs[cfg-1] (1-based as in SURVEY.md section 8d)."""
-    gens = {1: (double_integrator, 1), 2: (cartpole, 4096), 3: (quadrotor, 65536)}
+    gens = {1: (double_integrator, 1), 2: (cartpole, 4096), 3: (quadrotor, 65536), 4: (bicycle, 8192)}
     if cfg not in gens:
         raise ValueError(f"config {cfg} not available")
     fn, nb = gens[cfg]

@@ -94,13 +94,17 @@ int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
     auto A_ = [&](auto** ptr, size_t cnt) { if (rc == MPCQP_OK) rc = dev_alloc(h, ptr, cnt); };
     A_(&h->Gam, nm * p * n); A_(&h->QG, nm * p * n); A_(&h->Phi, nm * p * nx);
     A_(&h->H, nm * n * n); A_(&h->F, nm * n * nx); A_(&h->f0, nm * n);
-    A_(&h->d, n); A_(&h->Hs, n * n); A_(&h->M, n * n); A_(&h->Hi, n * n); A_(&h->W1, n * n);
-    A_(&h->W2, n * std::max(n, nx + 1));
-    A_(&h->Fs1, n * (nx + 1)); A_(&h->Ku1, n * (nx + 1));
-    A_(&h->FsT, (size_t)h->NP * (nx + 1)); A_(&h->KuT, (size_t)h->NP * (nx + 1));
+    // solver data: one copy for a shared model, one per model otherwise (W1, W2 are then only used when the
+    // factorisation does not fit LDS)
+    const bool w_in_lds = nm > 1 && 2 * n * n * sizeof(double) <= 96 * 1024;
+    A_(&h->d, nm * n); A_(&h->Hs, nm * n * n); A_(&h->M, n * n); A_(&h->Hi, nm * n * n);
+    A_(&h->W1, (w_in_lds ? 1 : nm) * n * n);
+    A_(&h->W2, (w_in_lds ? 1 : nm) * n * std::max(n, nx + 1));
+    A_(&h->Fs1, nm * n * (nx + 1)); A_(&h->Ku1, nm * n * (nx + 1));
+    A_(&h->FsT, nm * h->NP * (nx + 1)); A_(&h->KuT, nm * h->NP * (nx + 1));
     A_(&h->Mfrag, (size_t)h->NT * h->S * 64); A_(&h->Kbfrag, (size_t)h->NT * h->SX * 64);
     A_(&h->Kufrag, (size_t)h->NT * h->SX * 64);
-    A_(&h->lbs, h->NP); A_(&h->ubs, h->NP); A_(&h->rho_dev, 4); A_(&h->flag_dev, 4);
+    A_(&h->lbs, nm * h->NP); A_(&h->ubs, nm * h->NP); A_(&h->rho_dev, 4); A_(&h->flag_dev, 4);
     if (rc != MPCQP_OK) { g_create_err = h->err; mpcqp_destroy(h); return rc; }
     *out = h;
     return MPCQP_OK;
@@ -141,6 +145,17 @@ int mpcqp_set_constraints(mpcqp_handle h, const double* u_min, const double* u_m
     return MPCQP_OK;
 }
 
+int mpcqp_set_strides(mpcqp_handle h, long xref_stride, long uref_stride, long bound_stride) {
+    if (!h) return MPCQP_EINVAL;
+    if (xref_stride < 0 || uref_stride < 0 || bound_stride < 0) { h->err = "set_strides: strides must be >= 0"; return MPCQP_EINVAL; }
+    if (h->dims.n_models == 1 && (xref_stride || uref_stride || bound_stride)) {
+        h->err = "set_strides: per-model data needs n_models > 1"; return MPCQP_EINVAL;
+    }
+    h->xref_stride = xref_stride; h->uref_stride = uref_stride; h->bnd_stride = bound_stride;
+    h->assembled = h->factored = false;
+    return MPCQP_OK;
+}
+
 int mpcqp_assemble(mpcqp_handle h, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->A || !h->Q) { h->err = "assemble: set_model and set_cost first"; return MPCQP_ESTATE; }
@@ -154,18 +169,18 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->assembled) { h->err = "factor: assemble first"; return MPCQP_ESTATE; }
     if (!h->umin) { h->err = "factor: set_constraints first"; return MPCQP_ESTATE; }
-    if (h->dims.n_models != 1) { h->err = "factor: per-instance models are not implemented in this build"; return MPCQP_ENOTIMPL; }
     if (!admm_shared_box_supported(h->NT, h->S)) { h->err = "factor: N*nu > 128 is not implemented in this build"; return MPCQP_ENOTIMPL; }
     HIPCHK(h, hipSetDevice(h->dev));
     hipStream_t st = static_cast<hipStream_t>(stream);
-    TRY(launch_factor(h, opts ? opts->rho : 0.0, st));
+    if (h->dims.n_models > 1) TRY(launch_factor_batch(h, st));      // one model per instance: active-set path only
+    else TRY(launch_factor(h, opts ? opts->rho : 0.0, st));
     // set-up call: fetch rho and the failure flag (the only host synchronisation besides create)
     double r3[4]; int flag = 0;
     HIPCHK(h, hipMemcpyAsync(r3, h->rho_dev, sizeof(r3), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipMemcpyAsync(&flag, h->flag_dev, sizeof(int), hipMemcpyDeviceToHost, st));
     HIPCHK(h, hipStreamSynchronize(st));
     if (flag) { h->err = "factor: H is not positive definite (Cholesky pivot <= 0)"; return MPCQP_ENUMERIC; }
-    h->rho = r3[0];
+    h->rho = h->dims.n_models > 1 ? 1.0 : r3[0];
     h->inv_resid = r3[3];
     h->factored = true; h->has_state = false;
     return MPCQP_OK;
@@ -183,10 +198,15 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
     hipStream_t st = static_cast<hipStream_t>(stream);
     TRY(ensure_batch(h, batch));
     if (o.warm_start && h->has_state && batch != h->Blast) { h->err = "solve: warm start needs the same batch as the previous solve"; return MPCQP_EINVAL; }
-    if ((o.stages & 2) && !(o.stages & 1) && !(h->has_state && batch == h->Blast)) {
+    if (h->dims.n_models == 1 && (o.stages & 2) && !(o.stages & 1) && !(h->has_state && batch == h->Blast)) {
         h->err = "solve: stages=2 needs the state of a previous solve of the same batch"; return MPCQP_ESTATE;
     }
-    if (o.stages & 1) TRY(launch_admm_shared_box(h, x0, batch, o, st));
+    if (h->dims.n_models > 1) {
+        if (batch != h->dims.n_models) { h->err = "solve: with one model per instance the batch must equal n_models"; return MPCQP_EINVAL; }
+        if (!o.polish) { h->err = "solve: one model per instance is solved by the active-set kernel; polish cannot be off"; return MPCQP_EINVAL; }
+        o.stages = 2;       // no shared factor, hence no ADMM GEMM: the dual active-set kernel does the whole solve
+    }
+    if ((o.stages & 1) && h->dims.n_models == 1) TRY(launch_admm_shared_box(h, x0, batch, o, st));
     if (o.stages & 2) TRY(launch_polish_box(h, x0, batch, U, info, o, st));
     h->has_state = true; h->Blast = batch;
     return MPCQP_OK;
@@ -202,6 +222,14 @@ int mpcqp_shift(mpcqp_handle h, void* stream) {
     return MPCQP_OK;
 }
 
+int mpcqp_recenter(mpcqp_handle h, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (!h->has_state) { h->err = "recenter: no solution state yet"; return MPCQP_ESTATE; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    HIPCHK(h, hipMemsetAsync(h->z, 0, (size_t)h->Blast * h->NP * sizeof(double), static_cast<hipStream_t>(stream)));
+    return MPCQP_OK;
+}
+
 int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, void* stream) {
     if (!h || !out) return MPCQP_EINVAL;
     const size_t n = h->n, p = h->p, nx = h->dims.nx;
@@ -213,10 +241,10 @@ int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, v
         case 2: src = h->f0 + model * n; len = n; break;
         case 3: src = h->Gam + model * p * n; len = p * n; break;
         case 4: src = h->Phi + model * p * nx; len = p * nx; break;
-        case 5: src = h->Hs; len = n * n; break;
+        case 5: src = h->Hs + (h->dims.n_models > 1 ? model * n * n : 0); len = n * n; break;
         case 6: src = h->M; len = n * n; break;
-        case 7: src = h->Hi; len = n * n; break;
-        case 8: src = h->d; len = n; break;
+        case 7: src = h->Hi + (h->dims.n_models > 1 ? model * n * n : 0); len = n * n; break;
+        case 8: src = h->d + (h->dims.n_models > 1 ? model * n : 0); len = n; break;
         case 9: src = h->rho_dev; len = 3; break;
         case 10: case 11: {
             if (!h->has_state) { h->err = "get: no solution state yet"; return MPCQP_ESTATE; }

@@ -18,6 +18,7 @@ namespace {
 
 struct AsmParams {
     const double *A, *B, *Q, *R, *P, *xref, *uref;
+    long xref_stride, uref_stride;       // doubles between the references of consecutive models (0: shared)
     double *Gam, *QG, *Phi, *H, *F, *f0;
     int nx, nu, N, n, p, tv;
 };
@@ -143,10 +144,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
         for (int i = tid; i < n; i += 256) {
             double s = 0.0;
             if (a.xref)
-                for (int r = 0; r < p; ++r) s -= QG[(size_t)r * n + i] * a.xref[r];
+                for (int r = 0; r < p; ++r) s -= QG[(size_t)r * n + i] * a.xref[(size_t)m * a.xref_stride + r];
             if (a.uref) {
                 const int st = i / nu;
-                for (int j = 0; j < nu; ++j) s -= a.R[(i % nu) * nu + j] * a.uref[st * nu + j];
+                for (int j = 0; j < nu; ++j) s -= a.R[(i % nu) * nu + j] * a.uref[(size_t)m * a.uref_stride + st * nu + j];
             }
             f0[i] = s;
         }
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
 int launch_assemble(mpcqp_handle h, hipStream_t st) {
     AsmParams a;
     a.A = h->A; a.B = h->B; a.Q = h->Q; a.R = h->R; a.P = h->P; a.xref = h->xref; a.uref = h->uref;
+    a.xref_stride = h->xref_stride; a.uref_stride = h->uref_stride;
     a.Gam = h->Gam; a.QG = h->QG; a.Phi = h->Phi; a.H = h->H; a.F = h->F; a.f0 = h->f0;
     a.nx = h->dims.nx; a.nu = h->dims.nu; a.N = h->dims.N; a.n = h->n; a.p = h->p; a.tv = h->dims.time_varying;
     const size_t lds = (size_t)(2 * a.nx * a.n + 2 * a.nx * a.nx) * sizeof(double);

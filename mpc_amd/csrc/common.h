@@ -28,6 +28,7 @@ struct mpcqp_handle_s {
     const double *A = nullptr, *B = nullptr, *Q = nullptr, *R = nullptr, *P = nullptr;
     const double *xref = nullptr, *uref = nullptr, *umin = nullptr, *umax = nullptr;
     int per_stage = 0;
+    long xref_stride = 0, uref_stride = 0, bnd_stride = 0;   // per-model data (n_models > 1): doubles between models, 0 = shared
     // per-model workspace (n_models copies)
     double *Gam = nullptr, *QG = nullptr, *Phi = nullptr;   // (p,n) (p,n) (p,nx)
     double *H = nullptr, *F = nullptr, *f0 = nullptr;       // (n,n) (n,nx) (n)
@@ -65,6 +66,7 @@ struct mpcqp_handle_s {
 // ---- launchers implemented in the kernel translation units ----------------------
 int launch_assemble(mpcqp_handle h, hipStream_t st);
 int launch_factor(mpcqp_handle h, double rho, hipStream_t st);
+int launch_factor_batch(mpcqp_handle h, hipStream_t st);
 int launch_admm_shared_box(mpcqp_handle h, const double* x0, int B, const mpcqp_solve_opts& o, hipStream_t st);
 int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
                       const mpcqp_solve_opts& o, hipStream_t st);

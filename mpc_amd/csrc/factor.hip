@@ -171,6 +171,96 @@ __global__ __launch_bounds__(256) void factor_kernel(FacParams f) {
     }
 }
 
+// ---- one model per instance (n_models > 1): no shared factor, so no ADMM GEMM form; each workgroup prepares what
+// the active-set kernel needs for ITS model: d, Hs, Hi = Hs^-1, [Fs|f0s]^T, [Ku|ku]^T, scaled bounds.
+struct FacBatchParams {
+    const double *H, *F, *f0, *umin, *umax;
+    double *d, *Hs, *Hi, *W1, *W2, *Fs1, *Ku1, *FsT, *KuT, *lbs, *ubs, *rho_dev;
+    int* flag;
+    int n, nx, nu, NP, per_stage, use_lds;
+    long bnd_stride;
+};
+
+__global__ __launch_bounds__(256) void factor_batch_kernel(FacBatchParams f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[256];
+    const int n = f.n, nx = f.nx, nx1 = f.nx + 1, NP = f.NP, tid = threadIdx.x;
+    const size_t m = blockIdx.x;
+    const double* H = f.H + m * n * n;
+    const double* F = f.F + m * n * nx;
+    const double* f0 = f.f0 + m * n;
+    double* d = f.d + m * n;
+    double* Hs = f.Hs + m * n * n;
+    double* Hi = f.Hi + m * n * n;
+    double* Fs1 = f.Fs1 + m * n * nx1;
+    double* Ku1 = f.Ku1 + m * n * nx1;
+    double* W1 = f.use_lds ? reinterpret_cast<double*>(smem) : f.W1 + m * n * n;
+    double* W2 = f.use_lds ? reinterpret_cast<double*>(smem) + (size_t)n * n : f.W2 + m * n * n;
+    __shared__ int lflag[1];
+    if (tid == 0) lflag[0] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const double hii = H[(size_t)i * n + i];
+        if (!(hii > 0.0)) { lflag[0] |= 1; d[i] = 1.0; }
+        else d[i] = 1.0 / sqrt(hii);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * n; idx += 256) {
+        const int i = idx / n, j = idx % n;
+        const double v = 0.5 * (H[idx] + H[(size_t)j * n + i]) * d[i] * d[j];
+        Hs[idx] = v;
+        W1[idx] = v;
+    }
+    __syncthreads();
+    chol_inplace(W1, n, lflag);
+    inverse_from_chol(W1, W2, Hi, n);
+    for (int idx = tid; idx < n * nx1; idx += 256) {
+        const int i = idx / nx1, c = idx % nx1;
+        Fs1[idx] = d[i] * (c < nx ? F[(size_t)i * nx + c] : f0[i]);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < n * nx1; idx += 256) {
+        const int i = idx / nx1, c = idx % nx1;
+        double su = 0.0;
+        for (int k = 0; k < n; ++k) su -= Hi[(size_t)i * n + k] * Fs1[(size_t)k * nx1 + c];
+        Ku1[idx] = su;
+    }
+    {   // max |Hs Hi - I| over all models (non-negative doubles order like their bit patterns)
+        double e = 0.0;
+        for (int idx = tid; idx < n * n; idx += 256) {
+            const int i = idx / n, j = idx % n;
+            double sacc = (i == j) ? -1.0 : 0.0;
+            for (int k = 0; k < n; ++k) sacc += Hs[(size_t)i * n + k] * Hi[(size_t)k * n + j];
+            e = fmax(e, fabs(sacc));
+        }
+        red[tid] = e; __syncthreads();
+        for (int sft = 128; sft > 0; sft >>= 1) { if (tid < sft) red[tid] = fmax(red[tid], red[tid + sft]); __syncthreads(); }
+        if (tid == 0) {
+            atomicMax(reinterpret_cast<unsigned long long*>(f.rho_dev + 3), (unsigned long long)__double_as_longlong(red[0]));
+            if (lflag[0]) atomicOr(f.flag, 1);
+        }
+        __syncthreads();
+    }
+    double* FsT = f.FsT + m * NP * nx1;
+    double* KuT = f.KuT + m * NP * nx1;
+    for (int idx = tid; idx < NP * nx1; idx += 256) {
+        const int c = idx / NP, i = idx % NP;
+        FsT[idx] = i < n ? Fs1[(size_t)i * nx1 + c] : 0.0;
+        KuT[idx] = i < n ? Ku1[(size_t)i * nx1 + c] : 0.0;
+    }
+    const double* umin = f.umin + m * f.bnd_stride;
+    const double* umax = f.umax + m * f.bnd_stride;
+    for (int i = tid; i < NP; i += 256) {
+        double lo = 0.0, hi = 0.0;
+        if (i < n) {
+            const int j = f.per_stage ? i : (i % f.nu);
+            lo = umin[j] / d[i];
+            hi = umax[j] / d[i];
+        }
+        f.lbs[m * NP + i] = lo; f.ubs[m * NP + i] = hi;
+    }
+}
+
 }  // namespace
 
 int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
@@ -184,5 +274,25 @@ int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
     hipLaunchKernelGGL(factor_kernel, dim3(1), dim3(256), 0, st, f);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("factor launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
+    return MPCQP_OK;
+}
+
+int launch_factor_batch(mpcqp_handle h, hipStream_t st) {
+    FacBatchParams f;
+    f.H = h->H; f.F = h->F; f.f0 = h->f0; f.umin = h->umin; f.umax = h->umax;
+    f.d = h->d; f.Hs = h->Hs; f.Hi = h->Hi; f.W1 = h->W1; f.W2 = h->W2; f.Fs1 = h->Fs1; f.Ku1 = h->Ku1;
+    f.FsT = h->FsT; f.KuT = h->KuT; f.lbs = h->lbs; f.ubs = h->ubs; f.rho_dev = h->rho_dev; f.flag = h->flag_dev;
+    f.n = h->n; f.nx = h->dims.nx; f.nu = h->dims.nu; f.NP = h->NP; f.per_stage = h->per_stage;
+    f.bnd_stride = h->bnd_stride;
+    const size_t lds = (size_t)2 * h->n * h->n * sizeof(double);
+    f.use_lds = lds <= 96 * 1024;
+    hipError_t e = hipMemsetAsync(h->rho_dev, 0, 4 * sizeof(double), st);
+    if (e == hipSuccess) e = hipMemsetAsync(h->flag_dev, 0, sizeof(int), st);
+    if (e == hipSuccess && f.use_lds)
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
+    hipLaunchKernelGGL(factor_batch_kernel, dim3(h->dims.n_models), dim3(256), f.use_lds ? lds : 0, st, f);
+    e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("factor (batch) launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
     return MPCQP_OK;
 }

@@ -162,7 +162,14 @@ __device__ int build_list(WaveLds<KMAX>& s, const int (&side)[2], int lane) {
 
 // one instance, one wave
 template <int KMAX>
-__device__ void polish_wave(const PolParams& p, const int inst, WaveLds<KMAX>& s, const int lane) {
+__device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>& s, const int lane) {
+    PolParams p = pin;
+    if (p.st_nn) {          // this instance's own model
+        p.Hs += (size_t)inst * p.st_nn; p.Hi += (size_t)inst * p.st_nn;
+        p.FsT += (size_t)inst * p.st_k; p.KuT += (size_t)inst * p.st_k;
+        p.lbs += (size_t)inst * p.st_np; p.ubs += (size_t)inst * p.st_np;
+        p.d += (size_t)inst * p.st_n;
+    }
     const int n = p.n;
     const double* Hi = p.Hi;
 
@@ -194,7 +201,7 @@ __device__ void polish_wave(const PolParams& p, const int inst, WaveLds<KMAX>& s
         const int j = lane + 64 * q;
         if (j < n) {
             lo[q] = p.lbs[j]; hi[q] = p.ubs[j];
-            const double zz = zb[j], ww = wb[j];
+            const double zz = p.cold ? 0.0 : zb[j], ww = p.cold ? 0.0 : wb[j];
             x[q] = zz;
             lam[q] = p.rho * ww;
             // (z, w) are recovered from the kernel's (v, c) state, so "at the bound" and "w != 0"
@@ -535,6 +542,10 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     p.prof = profbuf;
 #endif
     p.pass = 0;
+    const bool per_model = h->dims.n_models > 1;
+    p.st_nn = per_model ? (long)h->n * h->n : 0; p.st_k = per_model ? (long)h->NP * (h->dims.nx + 1) : 0;
+    p.st_np = per_model ? h->NP : 0; p.st_n = per_model ? h->n : 0;
+    p.cold = (per_model && !(o.warm_start && h->has_state)) ? 1 : 0;
     p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
     // int workspace beyond [iters | need_big | converged]: two instance queues and their counters
@@ -544,7 +555,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     // small active sets (the usual case): eight lanes per instance with Hs^-1 in LDS, two passes (polish_quad.hip);
     // what those cannot finish is queued in q2 for the wave-per-instance kernel.  Shapes the fast path does not
     // take (refinement requested, polish off, n > 128) run the wave-per-instance kernel on the whole batch.
-    int rc = launch_polish_quad(p, q1, q2, counters, st);
+    int rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st);
 #ifdef POLISH_PROF
     if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {
         unsigned long long pr[16]; int cn[2];

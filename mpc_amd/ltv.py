@@ -1,0 +1,89 @@
+"""Closed-loop LTV MPC by re-linearisation about the shifted previous plan (BASELINE.json config 4:
+kinematic bicycle, warm-start shifting, many parallel rollouts).
+
+Reference counterpart: the sequential-QP loops that re-pose the QP around the previous answer and add the
+increment back (`D = D + optX`, CollocationBasedPlanner2D.py:85-365; `f += delf`, SE3Planner.py:103-223).
+Here every rollout has its OWN linearisation (one model per instance), all of them are assembled, factored
+and solved by the HIP library in one call each; this module only holds the scenario physics (the nonlinear
+model and its Jacobians, batched torch ops on the device) -- the part the reference keeps in its scripts too.
+"""
+from __future__ import annotations
+
+import torch
+
+from .planner import Planner
+
+
+class Bicycle:
+    """Kinematic bicycle, state (x, y, psi, v), input (a, delta), explicit Euler with step dt."""
+    nx, nu = 4, 2
+
+    def __init__(self, L=2.7, dt=0.05):
+        self.L, self.dt = float(L), float(dt)
+
+    def step(self, x, u):
+        px, py, psi, v = x.unbind(-1)
+        a, delta = u.unbind(-1)
+        dt, L = self.dt, self.L
+        return torch.stack((px + dt * v * torch.cos(psi), py + dt * v * torch.sin(psi),
+                            psi + dt * v / L * torch.tan(delta), v + dt * a), dim=-1)
+
+    def jacobians(self, x, u):
+        """A = df/dx (..., 4, 4), B = df/du (..., 4, 2) at (x, u)."""
+        psi, v = x[..., 2], x[..., 3]
+        delta = u[..., 1]
+        dt, L = self.dt, self.L
+        A = torch.eye(4, dtype=x.dtype, device=x.device).expand(x.shape[:-1] + (4, 4)).clone()
+        A[..., 0, 2] = -dt * v * torch.sin(psi); A[..., 0, 3] = dt * torch.cos(psi)
+        A[..., 1, 2] = dt * v * torch.cos(psi);  A[..., 1, 3] = dt * torch.sin(psi)
+        A[..., 2, 3] = dt * torch.tan(delta) / L
+        B = torch.zeros(x.shape[:-1] + (4, 2), dtype=x.dtype, device=x.device)
+        B[..., 2, 1] = dt * v / (L * torch.cos(delta) ** 2)
+        B[..., 3, 0] = dt
+        return A, B
+
+
+class ClosedLoopLTV:
+    """Receding-horizon loop: nominal rollout of the shifted plan -> per-instance (A_k, B_k) -> QP in the input
+    increments (x_ref - x_nominal, -u_nominal, bounds - u_nominal) -> apply the first input -> shift."""
+
+    def __init__(self, model, N, Q, R, P, u_min, u_max, device="cuda:0"):
+        self.model, self.N = model, int(N)
+        self.device = torch.device(device)
+        self.pl = Planner(model.nx, model.nu, self.N, device=self.device)
+        f64 = dict(dtype=torch.float64, device=self.device)
+        self.Q, self.R, self.P = (torch.as_tensor(m, **f64) for m in (Q, R, P))
+        self.u_min = torch.as_tensor(u_min, **f64).reshape(1, 1, model.nu)
+        self.u_max = torch.as_tensor(u_max, **f64).reshape(1, 1, model.nu)
+        self.plan = None            # (B, N, nu) current input plan
+        self.last = None            # tensors of the last QP, kept for inspection
+
+    def nominal(self, x, plan):
+        xs = [x]
+        for k in range(self.N):
+            xs.append(self.model.step(xs[-1], plan[:, k]))
+        return torch.stack(xs, dim=1)           # (B, N+1, nx)
+
+    def step(self, x, x_ref, warm=True, **opts):
+        """x (B,nx) current states, x_ref (B,N,nx) references for x_1..x_N.  Returns the applied input (B,nu)."""
+        Bn = x.shape[0]
+        first = self.plan is None
+        if first:
+            self.plan = torch.zeros((Bn, self.N, self.model.nu), dtype=torch.float64, device=self.device)
+        ubar = self.plan
+        xbar = self.nominal(x, ubar)
+        A, Bm = self.model.jacobians(xbar[:, :-1], ubar)
+        pl = self.pl
+        pl.set_model(A, Bm)
+        pl.set_cost(self.Q, self.R, self.P, x_ref=(x_ref - xbar[:, 1:]).contiguous(), u_ref=(-ubar).contiguous())
+        pl.set_constraints((self.u_min - ubar).contiguous(), (self.u_max - ubar).contiguous())
+        dx0 = torch.zeros((Bn, self.model.nx), dtype=torch.float64, device=self.device)
+        dU = pl.solve(dx0, warm_start=(warm and not first), **opts)
+        self.last = dict(xbar=xbar, ubar=ubar, A=A, B=Bm, x_ref=x_ref, dU=dU)
+        plan = ubar + dU
+        u0 = plan[:, 0].clone()
+        # shift: drop the applied stage, repeat the last one; the kept multipliers move the same way and the
+        # primal state is re-centred (the shifted plan is the origin of the next QP)
+        self.plan = torch.cat((plan[:, 1:], plan[:, -1:]), dim=1).contiguous()
+        pl.shift().recenter()
+        return u0

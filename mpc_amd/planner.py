@@ -77,6 +77,7 @@ class Planner:
             self._push_cost()
         if "u_min" in self._keep:
             self._push_constraints()
+        self._push_strides()
 
     def close(self):
         if self._h is not None:
@@ -97,28 +98,48 @@ class Planner:
 
     # ---- problem data ----------------------------------------------------------------
     def set_model(self, A, B):
-        """A: (nx,nx) | (N,nx,nx) | (1,N,nx,nx);  B likewise with nu columns.
-        A leading batch dimension > 1 (one model per instance) is not implemented yet."""
+        """A: (nx,nx) | (N,nx,nx) | (b, N|1, nx, nx) with b = 1 (shared) or b = batch (one model per instance,
+        e.g. an LTV re-linearisation about each instance's own trajectory);  B likewise with nu columns."""
         A = _as_dev(A, self.device); B = _as_dev(B, self.device)
         nx, nu, N = self.nx, self.nu, self.N
+        nm = 1
         if A.dim() == 2:
             tv = False
         elif A.dim() == 3:
             tv = True
         elif A.dim() == 4:
-            if A.shape[0] != 1:
-                raise NotImplementedError("per-instance models (leading batch dimension > 1) are not implemented yet")
-            A = A[0]; B = B[0] if B.dim() == 4 else B
-            tv = True
+            if B.dim() != 4 or B.shape[0] != A.shape[0] or B.shape[1] != A.shape[1]:
+                raise ValueError("A and B must have the same leading (batch, stage) dimensions")
+            nm = int(A.shape[0])
+            tv = A.shape[1] != 1
+            if tv and A.shape[1] != N:
+                raise ValueError(f"A: stage dimension must be 1 or N={N}")
         else:
             raise ValueError("A must have 2, 3 or 4 dimensions")
-        A = A.reshape((N, nx, nx) if tv else (nx, nx)).contiguous()
-        B = B.reshape((N, nx, nu) if tv else (nx, nu)).contiguous()
+        lead = (nm,) if nm > 1 else ()
+        A = A.reshape(lead + ((N, nx, nx) if tv else (nx, nx))).contiguous()
+        B = B.reshape(lead + ((N, nx, nu) if tv else (nx, nu))).contiguous()
         self._keep["A"], self._keep["B"] = A, B
-        self._create(1, tv)
+        self._create(nm, tv)
         self._check(self._lib.mpcqp_set_model(self._h, _ptr(A), _ptr(B)))
+        self._push_strides()
         self._dirty = True
         return self
+
+    def _push_strides(self):
+        if self._h is None:
+            return
+        k = self._keep
+        if self._n_models == 1:
+            if any(k.get(s, 0) for s in ("xref_stride", "uref_stride", "bnd_stride")):
+                raise ValueError("per-instance references / bounds need a per-instance model (leading batch dimension)")
+            return
+        for name in ("x_ref", "u_ref", "u_min"):
+            t = k.get(name)
+            if t is not None and t.dim() == 3 and t.shape[0] != self._n_models:
+                raise ValueError(f"{name}: leading dimension {t.shape[0]} != number of models {self._n_models}")
+        self._check(self._lib.mpcqp_set_strides(self._h, k.get("xref_stride", 0), k.get("uref_stride", 0),
+                                                k.get("bnd_stride", 0)))
 
     def _push_cost(self):
         k = self._keep
@@ -126,16 +147,28 @@ class Planner:
                                              _ptr(k.get("x_ref")), _ptr(k.get("u_ref"))))
 
     def set_cost(self, Q, R, P_terminal=None, x_ref=None, u_ref=None):
-        """Q (nx,nx), R (nu,nu), P_terminal (nx,nx, default Q); x_ref (N,nx) for x_1..x_N, u_ref (N,nu)."""
+        """Q (nx,nx), R (nu,nu), P_terminal (nx,nx, default Q); x_ref (N,nx) for x_1..x_N, u_ref (N,nu);
+        with one model per instance the references may carry a leading batch dimension."""
         nx, nu, N = self.nx, self.nu, self.N
         k = self._keep
         k["Q"] = _as_dev(Q, self.device, (nx, nx), "Q")
         k["R"] = _as_dev(R, self.device, (nu, nu), "R")
         k["P"] = _as_dev(Q if P_terminal is None else P_terminal, self.device, (nx, nx), "P_terminal")
-        k["x_ref"] = _as_dev(x_ref, self.device, (N, nx), "x_ref")
-        k["u_ref"] = _as_dev(u_ref, self.device, (N, nu), "u_ref")
+        for name, val, cols in (("x_ref", x_ref, nx), ("u_ref", u_ref, nu)):
+            t = _as_dev(val, self.device)
+            stride = 0
+            if t is not None:
+                if t.dim() == 3:
+                    if tuple(t.shape[1:]) != (N, cols):
+                        raise ValueError(f"{name}: expected (batch, {N}, {cols}), got {tuple(t.shape)}")
+                    stride = N * cols
+                elif tuple(t.shape) != (N, cols):
+                    raise ValueError(f"{name}: expected shape {(N, cols)}, got {tuple(t.shape)}")
+            k[name] = t
+            k["xref_stride" if name == "x_ref" else "uref_stride"] = stride
         if self._h is not None:
             self._push_cost()
+            self._push_strides()
         self._dirty = True
         return self
 
@@ -149,19 +182,27 @@ class Planner:
         if any(v is not None for v in (x_min, x_max, C, c_min, c_max)):
             raise NotImplementedError("state-box / polytopic constraints are not implemented yet")
         u_min = _as_dev(u_min, self.device); u_max = _as_dev(u_max, self.device)
-        if u_min.numel() == self.nu:
+        if tuple(u_min.shape) != tuple(u_max.shape):
+            raise ValueError("u_min and u_max must have the same shape")
+        bnd_stride = 0
+        if u_min.dim() == 3:                    # (batch, N, nu): one set of bounds per instance
+            if tuple(u_min.shape[1:]) != (self.N, self.nu):
+                raise ValueError(f"u_min/u_max: expected (batch, {self.N}, {self.nu})")
+            per_stage, bnd_stride = 1, self.n
+        elif u_min.numel() == self.nu:
             per_stage = 0
             u_min = u_min.reshape(self.nu); u_max = u_max.reshape(self.nu)
         elif u_min.numel() == self.n:
             per_stage = 1
             u_min = u_min.reshape(self.n); u_max = u_max.reshape(self.n)
         else:
-            raise ValueError("u_min/u_max must have nu or N*nu elements")
+            raise ValueError("u_min/u_max must have nu or N*nu elements (or a leading batch dimension)")
         if bool((u_min > u_max).any()):
             raise ValueError("u_min > u_max")
-        self._keep.update(u_min=u_min.contiguous(), u_max=u_max.contiguous(), per_stage=per_stage)
+        self._keep.update(u_min=u_min.contiguous(), u_max=u_max.contiguous(), per_stage=per_stage, bnd_stride=bnd_stride)
         if self._h is not None:
             self._push_constraints()
+            self._push_strides()
         self._dirty = True
         return self
 
@@ -218,11 +259,17 @@ class Planner:
         self._check(self._lib.mpcqp_shift(self._h, self._stream()))
         return self
 
+    def recenter(self):
+        """Deviation-form re-linearisation: zero the kept primal state (the shifted plan becomes the origin of
+        the next QP), keep the multipliers as the active-set guess."""
+        self._check(self._lib.mpcqp_recenter(self._h, self._stream()))
+        return self
+
     # ---- introspection -------------------------------------------------------------------
     _GET = {"H": 0, "F": 1, "f0": 2, "Gamma": 3, "Phi": 4, "Hs": 5, "M": 6, "Hi": 7, "d": 8, "rho": 9,
             "z": 10, "w": 11}
 
-    def get(self, name, batch=None):
+    def get(self, name, batch=None, model=0):
         n, p, nx = self.n, self.N * self.nx, self.nx
         shapes = {"H": (n, n), "F": (n, nx), "f0": (n,), "Gamma": (p, n), "Phi": (p, nx), "Hs": (n, n),
                   "M": (n, n), "Hi": (n, n), "d": (n,), "rho": (3,)}
@@ -233,5 +280,5 @@ class Planner:
         else:
             shape = shapes[name]
         out = torch.empty(shape, dtype=torch.float64, device=self.device)
-        self._check(self._lib.mpcqp_get(self._h, self._GET[name], 0, _ptr(out), out.numel(), self._stream()))
+        self._check(self._lib.mpcqp_get(self._h, self._GET[name], int(model), _ptr(out), out.numel(), self._stream()))
         return out
