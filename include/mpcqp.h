@@ -62,6 +62,9 @@ typedef struct mpcqp_dims {
 
 typedef struct mpcqp_factor_opts {
     double rho;        /* ADMM penalty in Jacobi-scaled variables; <= 0: pick from the spectrum */
+    int    no_sync;    /* 1: do not synchronise the stream to report rho / a failed factorisation to the host
+                          (needs rho > 0 or n_models > 1); failures then show up as per-instance status     */
+    int    keep_state; /* 1: the kept (z, w) stays valid across this re-factorisation (closed loop, warm start) */
 } mpcqp_factor_opts;
 
 typedef struct mpcqp_solve_opts {
@@ -152,6 +155,16 @@ int  mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const doub
                        const double* G, const double* h, const double* A, const double* b,
                        double* x, double* z, double* y, double* obj, int* status, int* iters,
                        double* workspace, int* int_workspace, void* stream);
+
+/* -- scenario model for the closed-loop LTV configuration (BASELINE.json configs[3]; the reference has no counterpart:
+ * its scripts keep the model code inline, e.g. CollocationBasedPlanner2D.py:88-347) --------------------------------
+ * Kinematic bicycle, state (x, y, psi, v), input (a, delta), explicit Euler.  For every rollout: nominal trajectory
+ * xbar (batch, N+1, 4) of `plan` (batch, N, 2) from x (batch, 4); Jacobians A (batch, N, 4, 4), B (batch, N, 4, 2);
+ * and the data of the QP in input increments: xref_dev = x_ref - xbar[1:], uref_dev = -plan, lb/ub = u_min/u_max - plan
+ * (all (batch, N, .)).  Feed them to mpcqp_set_model / set_cost / set_constraints / set_strides with n_models = batch. */
+int mpcqp_ltv_bicycle(int device_id, int batch, int N, double dt, double L, const double* x, const double* plan,
+                      const double* x_ref, const double* u_min, const double* u_max, double* xbar, double* A,
+                      double* B, double* xref_dev, double* uref_dev, double* lb, double* ub, void* stream);
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,7 @@ class Dims(C.Structure):
 
 
 class FactorOpts(C.Structure):
-    _fields_ = [("rho", C.c_double)]
+    _fields_ = [("rho", C.c_double), ("no_sync", C.c_int), ("keep_state", C.c_int)]
 
 
 class SolveOpts(C.Structure):
@@ -54,6 +54,7 @@ SYMBOLS = [
     ("mpcqp_recenter", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_get", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),
+    ("mpcqp_ltv_bicycle", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 13),
     ("mpcqp_solve_dense", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 14 + [C.c_void_p]),
 ]
 

@@ -96,7 +96,7 @@ int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
     A_(&h->H, nm * n * n); A_(&h->F, nm * n * nx); A_(&h->f0, nm * n);
     // solver data: one copy for a shared model, one per model otherwise (W1, W2 are then only used when the
     // factorisation does not fit LDS)
-    const bool w_in_lds = nm > 1 && 2 * n * n * sizeof(double) <= 96 * 1024;
+    const bool w_in_lds = nm > 1 && 4 * n * n * sizeof(double) <= 128 * 1024;
     A_(&h->d, nm * n); A_(&h->Hs, nm * n * n); A_(&h->M, n * n); A_(&h->Hi, nm * n * n);
     A_(&h->W1, (w_in_lds ? 1 : nm) * n * n);
     A_(&h->W2, (w_in_lds ? 1 : nm) * n * std::max(n, nx + 1));
@@ -104,7 +104,7 @@ int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
     A_(&h->FsT, nm * h->NP * (nx + 1)); A_(&h->KuT, nm * h->NP * (nx + 1));
     A_(&h->Mfrag, (size_t)h->NT * h->S * 64); A_(&h->Kbfrag, (size_t)h->NT * h->SX * 64);
     A_(&h->Kufrag, (size_t)h->NT * h->SX * 64);
-    A_(&h->lbs, nm * h->NP); A_(&h->ubs, nm * h->NP); A_(&h->rho_dev, 4); A_(&h->flag_dev, 4);
+    A_(&h->lbs, nm * h->NP); A_(&h->ubs, nm * h->NP); A_(&h->rho_dev, 4); A_(&h->flag_dev, 4); A_(&h->mflag, nm);
     if (rc != MPCQP_OK) { g_create_err = h->err; mpcqp_destroy(h); return rc; }
     *out = h;
     return MPCQP_OK;
@@ -114,7 +114,7 @@ int mpcqp_destroy(mpcqp_handle h) {
     if (!h) return MPCQP_OK;
     (void)hipSetDevice(h->dev);
     void* ptrs[] = {h->Gam, h->QG, h->Phi, h->H, h->F, h->f0, h->d, h->Hs, h->M, h->Hi, h->W1, h->W2, h->Fs1,
-                    h->Ku1, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev,
+                    h->Ku1, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev, h->mflag,
                     h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
@@ -174,6 +174,13 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (h->dims.n_models > 1) TRY(launch_factor_batch(h, st));      // one model per instance: active-set path only
     else TRY(launch_factor(h, opts ? opts->rho : 0.0, st));
+    if (opts && opts->no_sync && (h->dims.n_models > 1 || opts->rho > 0.0)) {
+        // closed-loop use: no host round trip.  A failed factorisation is then reported per instance by the
+        // solve (status MPCQP_MAX_ITER); whether the polish refines follows the last synchronous factor call.
+        h->rho = h->dims.n_models > 1 ? 1.0 : opts->rho;
+        h->factored = true; h->has_state = h->has_state && opts->keep_state;
+        return MPCQP_OK;
+    }
     // set-up call: fetch rho and the failure flag (the only host synchronisation besides create)
     double r3[4]; int flag = 0;
     HIPCHK(h, hipMemcpyAsync(r3, h->rho_dev, sizeof(r3), hipMemcpyDeviceToHost, st));
@@ -182,7 +189,7 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     if (flag) { h->err = "factor: H is not positive definite (Cholesky pivot <= 0)"; return MPCQP_ENUMERIC; }
     h->rho = h->dims.n_models > 1 ? 1.0 : r3[0];
     h->inv_resid = r3[3];
-    h->factored = true; h->has_state = false;
+    h->factored = true; h->has_state = h->has_state && opts && opts->keep_state;
     return MPCQP_OK;
 }
 

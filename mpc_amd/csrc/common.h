@@ -41,6 +41,7 @@ struct mpcqp_handle_s {
     double *lbs = nullptr, *ubs = nullptr;                  // (NP) scaled bounds, padded rows = 0
     double *rho_dev = nullptr;  // [0] rho, [1] lambda_max est, [2] lambda_min est
     int *flag_dev = nullptr;    // [0] != 0: factorisation failed
+    int *mflag = nullptr;       // [n_models]: this model's factorisation failed (its instances report MPCQP_MAX_ITER)
     double rho = 0.0;
     double inv_resid = 0.0;     // max |Hs Hi - I|: decides whether the polish refines by default
     // per-batch workspace (grow only)

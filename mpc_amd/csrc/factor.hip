@@ -33,10 +33,9 @@ __device__ void chol_inplace(double* W, int n, int* flag) {
         const double inv = 1.0 / W[(size_t)j * n + j];
         for (int i = j + 1 + tid; i < n; i += 256) W[(size_t)i * n + j] *= inv;
         __syncthreads();
-        const int rem = n - j - 1;
-        for (int idx = tid; idx < rem * rem; idx += 256) {
-            const int i = j + 1 + idx / rem, k = j + 1 + idx % rem;
-            if (k <= i) W[(size_t)i * n + k] -= W[(size_t)i * n + j] * W[(size_t)k * n + j];
+        for (int i = j + 1 + (tid >> 6); i < n; i += 4) {       // a wave per row, lanes along the columns
+            const double lij = W[(size_t)i * n + j];
+            for (int k = j + 1 + (tid & 63); k <= i; k += 64) W[(size_t)i * n + k] -= lij * W[(size_t)k * n + j];
         }
         __syncthreads();
     }
@@ -176,7 +175,7 @@ __global__ __launch_bounds__(256) void factor_kernel(FacParams f) {
 struct FacBatchParams {
     const double *H, *F, *f0, *umin, *umax;
     double *d, *Hs, *Hi, *W1, *W2, *Fs1, *Ku1, *FsT, *KuT, *lbs, *ubs, *rho_dev;
-    int* flag;
+    int *flag, *mflag;                  // any model failed / per model
     int n, nx, nu, NP, per_stage, use_lds;
     long bnd_stride;
 };
@@ -184,19 +183,24 @@ struct FacBatchParams {
 __global__ __launch_bounds__(256) void factor_batch_kernel(FacBatchParams f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ double red[256];
+    __shared__ int lflag[1];
     const int n = f.n, nx = f.nx, nx1 = f.nx + 1, NP = f.NP, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
     const size_t m = blockIdx.x;
     const double* H = f.H + m * n * n;
     const double* F = f.F + m * n * nx;
     const double* f0 = f.f0 + m * n;
     double* d = f.d + m * n;
-    double* Hs = f.Hs + m * n * n;
-    double* Hi = f.Hi + m * n * n;
+    double* gHs = f.Hs + m * n * n;
+    double* gHi = f.Hi + m * n * n;
     double* Fs1 = f.Fs1 + m * n * nx1;
     double* Ku1 = f.Ku1 + m * n * nx1;
-    double* W1 = f.use_lds ? reinterpret_cast<double*>(smem) : f.W1 + m * n * n;
-    double* W2 = f.use_lds ? reinterpret_cast<double*>(smem) + (size_t)n * n : f.W2 + m * n * n;
-    __shared__ int lflag[1];
+    // LDS: Hs, L (in place), L^-1, Hi, d  -- or, when 4 n^2 doubles do not fit, the global scratch and outputs
+    double* sm = reinterpret_cast<double*>(smem);
+    double* Hs = f.use_lds ? sm : gHs;
+    double* W1 = f.use_lds ? sm + (size_t)n * n : f.W1 + m * n * n;
+    double* W2 = f.use_lds ? sm + (size_t)2 * n * n : f.W2 + m * n * n;
+    double* Hi = f.use_lds ? sm + (size_t)3 * n * n : gHi;
     if (tid == 0) lflag[0] = 0;
     __syncthreads();
     for (int i = tid; i < n; i += 256) {
@@ -205,49 +209,52 @@ __global__ __launch_bounds__(256) void factor_batch_kernel(FacBatchParams f) {
         else d[i] = 1.0 / sqrt(hii);
     }
     __syncthreads();
-    for (int idx = tid; idx < n * n; idx += 256) {
-        const int i = idx / n, j = idx % n;
-        const double v = 0.5 * (H[idx] + H[(size_t)j * n + i]) * d[i] * d[j];
-        Hs[idx] = v;
-        W1[idx] = v;
-    }
+    for (int i = wave; i < n; i += 4)
+        for (int j = lane; j < n; j += 64) {
+            const double v = 0.5 * (H[(size_t)i * n + j] + H[(size_t)j * n + i]) * d[i] * d[j];
+            Hs[i * n + j] = v;
+            W1[i * n + j] = v;
+        }
     __syncthreads();
     chol_inplace(W1, n, lflag);
     inverse_from_chol(W1, W2, Hi, n);
     for (int idx = tid; idx < n * nx1; idx += 256) {
-        const int i = idx / nx1, c = idx % nx1;
+        const int i = idx / nx1, c = idx - i * nx1;
         Fs1[idx] = d[i] * (c < nx ? F[(size_t)i * nx + c] : f0[i]);
     }
     __syncthreads();
     for (int idx = tid; idx < n * nx1; idx += 256) {
-        const int i = idx / nx1, c = idx % nx1;
+        const int i = idx / nx1, c = idx - i * nx1;
         double su = 0.0;
-        for (int k = 0; k < n; ++k) su -= Hi[(size_t)i * n + k] * Fs1[(size_t)k * nx1 + c];
+        for (int k = 0; k < n; ++k) su -= Hi[i * n + k] * Fs1[(size_t)k * nx1 + c];
         Ku1[idx] = su;
     }
     {   // max |Hs Hi - I| over all models (non-negative doubles order like their bit patterns)
         double e = 0.0;
-        for (int idx = tid; idx < n * n; idx += 256) {
-            const int i = idx / n, j = idx % n;
-            double sacc = (i == j) ? -1.0 : 0.0;
-            for (int k = 0; k < n; ++k) sacc += Hs[(size_t)i * n + k] * Hi[(size_t)k * n + j];
-            e = fmax(e, fabs(sacc));
-        }
+        for (int i = wave; i < n; i += 4)
+            for (int j = lane; j < n; j += 64) {
+                double sacc = (i == j) ? -1.0 : 0.0;
+                for (int k = 0; k < n; ++k) sacc += Hs[i * n + k] * Hi[k * n + j];
+                e = fmax(e, fabs(sacc));
+            }
         red[tid] = e; __syncthreads();
         for (int sft = 128; sft > 0; sft >>= 1) { if (tid < sft) red[tid] = fmax(red[tid], red[tid + sft]); __syncthreads(); }
         if (tid == 0) {
             atomicMax(reinterpret_cast<unsigned long long*>(f.rho_dev + 3), (unsigned long long)__double_as_longlong(red[0]));
             if (lflag[0]) atomicOr(f.flag, 1);
+            f.mflag[m] = lflag[0];
         }
         __syncthreads();
     }
+    if (f.use_lds)
+        for (int idx = tid; idx < n * n; idx += 256) { gHs[idx] = Hs[idx]; gHi[idx] = Hi[idx]; }
     double* FsT = f.FsT + m * NP * nx1;
     double* KuT = f.KuT + m * NP * nx1;
-    for (int idx = tid; idx < NP * nx1; idx += 256) {
-        const int c = idx / NP, i = idx % NP;
-        FsT[idx] = i < n ? Fs1[(size_t)i * nx1 + c] : 0.0;
-        KuT[idx] = i < n ? Ku1[(size_t)i * nx1 + c] : 0.0;
-    }
+    for (int c = wave; c < nx1; c += 4)
+        for (int i = lane; i < NP; i += 64) {
+            FsT[c * NP + i] = i < n ? Fs1[(size_t)i * nx1 + c] : 0.0;
+            KuT[c * NP + i] = i < n ? Ku1[(size_t)i * nx1 + c] : 0.0;
+        }
     const double* umin = f.umin + m * f.bnd_stride;
     const double* umax = f.umax + m * f.bnd_stride;
     for (int i = tid; i < NP; i += 256) {
@@ -284,8 +291,9 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st) {
     f.FsT = h->FsT; f.KuT = h->KuT; f.lbs = h->lbs; f.ubs = h->ubs; f.rho_dev = h->rho_dev; f.flag = h->flag_dev;
     f.n = h->n; f.nx = h->dims.nx; f.nu = h->dims.nu; f.NP = h->NP; f.per_stage = h->per_stage;
     f.bnd_stride = h->bnd_stride;
-    const size_t lds = (size_t)2 * h->n * h->n * sizeof(double);
-    f.use_lds = lds <= 96 * 1024;
+    const size_t lds = (size_t)4 * h->n * h->n * sizeof(double);
+    f.use_lds = lds <= 128 * 1024;
+    f.mflag = h->mflag;
     hipError_t e = hipMemsetAsync(h->rho_dev, 0, 4 * sizeof(double), st);
     if (e == hipSuccess) e = hipMemsetAsync(h->flag_dev, 0, sizeof(int), st);
     if (e == hipSuccess && f.use_lds)

@@ -214,9 +214,9 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
 
     int status = MPCQP_SOLVED_INACCURATE;
     int steps = 0;
-    bool overflow = false, fail = false;
+    bool overflow = false, fail = (p.mflag != nullptr) && p.mflag[inst] != 0;
 
-    if (p.polish) {
+    if (p.polish && !fail) {
         // ---- warm phase: solve on the guessed set, release wrong-signed multipliers -------------
         int k = 0;
         for (;;) {
@@ -546,6 +546,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     p.st_nn = per_model ? (long)h->n * h->n : 0; p.st_k = per_model ? (long)h->NP * (h->dims.nx + 1) : 0;
     p.st_np = per_model ? h->NP : 0; p.st_n = per_model ? h->n : 0;
     p.cold = (per_model && !(o.warm_start && h->has_state)) ? 1 : 0;
+    p.mflag = per_model ? h->mflag : nullptr;
     p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
     // int workspace beyond [iters | need_big | converged]: two instance queues and their counters

@@ -53,16 +53,43 @@ class ClosedLoopLTV:
         self.pl = Planner(model.nx, model.nu, self.N, device=self.device)
         f64 = dict(dtype=torch.float64, device=self.device)
         self.Q, self.R, self.P = (torch.as_tensor(m, **f64) for m in (Q, R, P))
-        self.u_min = torch.as_tensor(u_min, **f64).reshape(1, 1, model.nu)
-        self.u_max = torch.as_tensor(u_max, **f64).reshape(1, 1, model.nu)
+        self.u_min = torch.as_tensor(u_min, **f64).reshape(1, 1, model.nu).contiguous()
+        self.u_max = torch.as_tensor(u_max, **f64).reshape(1, 1, model.nu).contiguous()
         self.plan = None            # (B, N, nu) current input plan
         self.last = None            # tensors of the last QP, kept for inspection
+        self._dx0 = None
 
     def nominal(self, x, plan):
         xs = [x]
         for k in range(self.N):
             xs.append(self.model.step(xs[-1], plan[:, k]))
         return torch.stack(xs, dim=1)           # (B, N+1, nx)
+
+    def linearize(self, x, ubar, x_ref):
+        """nominal rollout, Jacobians and the deviation-form QP data: one HIP kernel for the bicycle, batched
+        torch ops for any other model object with step()/jacobians()."""
+        Bn, N, nx, nu = x.shape[0], self.N, self.model.nx, self.model.nu
+        if isinstance(self.model, Bicycle):
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            f64 = dict(dtype=torch.float64, device=self.device)
+            out = dict(xbar=torch.empty((Bn, N + 1, nx), **f64), A=torch.empty((Bn, N, nx, nx), **f64),
+                       B=torch.empty((Bn, N, nx, nu), **f64), xr=torch.empty((Bn, N, nx), **f64),
+                       ur=torch.empty((Bn, N, nu), **f64), lb=torch.empty((Bn, N, nu), **f64),
+                       ub=torch.empty((Bn, N, nu), **f64))
+            p = lambda t: C.c_void_p(t.data_ptr())
+            rc = lib.mpcqp_ltv_bicycle(self.device.index or 0, Bn, N, self.model.dt, self.model.L, p(x.contiguous()),
+                                       p(ubar), p(x_ref.contiguous()), p(self.u_min), p(self.u_max), p(out["xbar"]),
+                                       p(out["A"]), p(out["B"]), p(out["xr"]), p(out["ur"]), p(out["lb"]), p(out["ub"]),
+                                       C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"mpcqp_ltv_bicycle failed with code {rc}")
+            return out
+        xbar = self.nominal(x, ubar)
+        A, Bm = self.model.jacobians(xbar[:, :-1], ubar)
+        return dict(xbar=xbar, A=A, B=Bm, xr=(x_ref - xbar[:, 1:]).contiguous(), ur=(-ubar).contiguous(),
+                    lb=(self.u_min - ubar).contiguous(), ub=(self.u_max - ubar).contiguous())
 
     def step(self, x, x_ref, warm=True, **opts):
         """x (B,nx) current states, x_ref (B,N,nx) references for x_1..x_N.  Returns the applied input (B,nu)."""
@@ -71,19 +98,21 @@ class ClosedLoopLTV:
         if first:
             self.plan = torch.zeros((Bn, self.N, self.model.nu), dtype=torch.float64, device=self.device)
         ubar = self.plan
-        xbar = self.nominal(x, ubar)
-        A, Bm = self.model.jacobians(xbar[:, :-1], ubar)
+        lin = self.linearize(x, ubar, x_ref)
         pl = self.pl
-        pl.set_model(A, Bm)
-        pl.set_cost(self.Q, self.R, self.P, x_ref=(x_ref - xbar[:, 1:]).contiguous(), u_ref=(-ubar).contiguous())
-        pl.set_constraints((self.u_min - ubar).contiguous(), (self.u_max - ubar).contiguous())
-        dx0 = torch.zeros((Bn, self.model.nx), dtype=torch.float64, device=self.device)
-        dU = pl.solve(dx0, warm_start=(warm and not first), **opts)
-        self.last = dict(xbar=xbar, ubar=ubar, A=A, B=Bm, x_ref=x_ref, dU=dU)
+        pl.set_model(lin["A"], lin["B"])
+        pl.set_cost(self.Q, self.R, self.P, x_ref=lin["xr"], u_ref=lin["ur"])
+        pl.set_constraints(lin["lb"], lin["ub"])
+        if self._dx0 is None or self._dx0.shape[0] != Bn:
+            self._dx0 = torch.zeros((Bn, self.model.nx), dtype=torch.float64, device=self.device)
+        dU = pl.solve(self._dx0, warm_start=(warm and not first), **opts)
+        self.last = dict(xbar=lin["xbar"], ubar=ubar, A=lin["A"], B=lin["B"], x_ref=x_ref, dU=dU)
         plan = ubar + dU
         u0 = plan[:, 0].clone()
         # shift: drop the applied stage, repeat the last one; the kept multipliers move the same way and the
         # primal state is re-centred (the shifted plan is the origin of the next QP)
         self.plan = torch.cat((plan[:, 1:], plan[:, -1:]), dim=1).contiguous()
         pl.shift().recenter()
+        # after the first (synchronous, validated) step the set-up calls no longer wait for the device
+        pl.no_sync, pl.check_inputs = True, False
         return u0

@@ -59,6 +59,8 @@ class Planner:
         self._dirty = True
         self.rho = None
         self.info = None
+        self.no_sync = False         # True: set-up calls never wait for the device (closed loops)
+        self.check_inputs = True     # False: skip the host-side sanity checks that synchronise (u_min <= u_max)
         self.opts = _lib.SolveOpts()
         self._lib.mpcqp_default_solve_opts(C.byref(self.opts))
 
@@ -197,7 +199,7 @@ class Planner:
             u_min = u_min.reshape(self.n); u_max = u_max.reshape(self.n)
         else:
             raise ValueError("u_min/u_max must have nu or N*nu elements (or a leading batch dimension)")
-        if bool((u_min > u_max).any()):
+        if self.check_inputs and bool((u_min > u_max).any()):
             raise ValueError("u_min > u_max")
         self._keep.update(u_min=u_min.contiguous(), u_max=u_max.contiguous(), per_stage=per_stage, bnd_stride=bnd_stride)
         if self._h is not None:
@@ -207,14 +209,16 @@ class Planner:
         return self
 
     # ---- kernels -----------------------------------------------------------------------
-    def setup(self, rho=None):
-        """assemble (rollout, H, F, f0) + factor; called lazily by solve()."""
+    def setup(self, rho=None, keep_state=False):
+        """assemble (rollout, H, F, f0) + factor; called lazily by solve().  With ``self.no_sync`` (closed loops)
+        the factor call does not wait for the device: a failed factorisation then shows up as per-instance status."""
         if self._h is None or "Q" not in self._keep or "u_min" not in self._keep:
             raise RuntimeError("set_model, set_cost and set_constraints must be called before solve")
         self._check(self._lib.mpcqp_assemble(self._h, self._stream()))
-        fo = _lib.FactorOpts(float(rho) if rho else 0.0)
+        no_sync = bool(self.no_sync and (self._n_models > 1 or rho))
+        fo = _lib.FactorOpts(float(rho) if rho else 0.0, int(no_sync), int(bool(keep_state)))
         self._check(self._lib.mpcqp_factor(self._h, C.byref(fo), self._stream()))
-        self.rho = float(self.get("rho")[0])
+        self.rho = (1.0 if self._n_models > 1 else float(rho)) if no_sync else float(self.get("rho")[0])
         self._dirty = False
         return self
 
@@ -225,7 +229,7 @@ class Planner:
         polish_max_steps; rho (forces a re-factor)."""
         rho = opts.pop("rho", None)
         if self._dirty or (rho is not None and rho != self.rho):
-            self.setup(rho)
+            self.setup(rho, keep_state=bool(warm_start))
         x0 = _as_dev(x0, self.device)
         if x0.dim() == 1:
             x0 = x0.reshape(1, -1)
