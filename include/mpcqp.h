@@ -156,6 +156,14 @@ int  mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const doub
                        double* x, double* z, double* y, double* obj, int* status, int* iters,
                        double* workspace, int* int_workspace, void* stream);
 
+/* the same with explicit strides (doubles between consecutive QPs; 0 = one array shared by the whole batch): the MPC
+ * case with state / polytopic rows has ONE Hessian and ONE constraint matrix [I; Gamma rows; C Gamma rows]
+ * (LaunchPlannerQPFormulation.py:94-121, Launch3DPlanner.py:115-160) and per-instance q = F x0 + f0, h = h0 - E x0 */
+int  mpcqp_solve_dense_strided(int device_id, int batch, int n, int m, int p, const double* P, long sP, const double* q,
+                               long sq, const double* G, long sG, const double* h, long sh, const double* A, long sA,
+                               const double* b, long sb, double* x, double* z, double* y, double* obj, int* status,
+                               int* iters, double* workspace, int* int_workspace, void* stream);
+
 /* -- scenario model for the closed-loop LTV configuration (BASELINE.json configs[3]; the reference has no counterpart:
  * its scripts keep the model code inline, e.g. CollocationBasedPlanner2D.py:88-347) --------------------------------
  * Kinematic bicycle, state (x, y, psi, v), input (a, delta), explicit Euler.  For every rollout: nominal trajectory

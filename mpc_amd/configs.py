@@ -94,9 +94,25 @@ def bicycle(batch=8192, seed=0, N=20, dt=0.05):
                 v_ref=5.0, x0=x0)
 
 
+def long_horizon(batch=256, seed=0, N=100, nx=20, nu=6):
+    """Config 5: random stable LTI (A = 0.95 * orthogonal, perturbed), input box + state box on all states +
+    2 nx random polytope rows per stage.  x0 is drawn small enough that the problem stays feasible."""
+    rng = np.random.default_rng(seed)
+    Qo, _ = np.linalg.qr(rng.standard_normal((nx, nx)))
+    A = 0.95 * Qo + 0.02 * rng.standard_normal((nx, nx))
+    B = rng.standard_normal((nx, nu)) / np.sqrt(nx)
+    Q = np.eye(nx); R = 0.1 * np.eye(nu)
+    P = sl.solve_discrete_are(A, B, Q, R)
+    C = rng.standard_normal((2 * nx, nx)) / np.sqrt(nx)
+    x0 = rng.uniform(-1.0, 1.0, (batch, nx))
+    return dict(name="long_horizon", nx=nx, nu=nu, N=N, A=A, B=B, Q=Q, R=R, P=P, u_min=-0.5 * np.ones(nu),
+                u_max=0.5 * np.ones(nu), x_min=-1.2 * np.ones(nx), x_max=1.2 * np.ones(nx), C=C,
+                c_min=-1.0 * np.ones(2 * nx), c_max=1.0 * np.ones(2 * nx), x0=x0)
+
+
 def make_config(cfg, batch=None, seed=0):
     """BASELINE.json configs[cfg-1] (1-based as in SURVEY.md section 8d)."""
-    gens = {1: (double_integrator, 1), 2: (cartpole, 4096), 3: (quadrotor, 65536), 4: (bicycle, 8192)}
+    gens = {1: (double_integrator, 1), 2: (cartpole, 4096), 3: (quadrotor, 65536), 4: (bicycle, 8192), 5: (long_horizon, 256)}
     if cfg not in gens:
         raise ValueError(f"config {cfg} not available")
     fn, nb = gens[cfg]

@@ -23,6 +23,7 @@ namespace {
 
 struct DenseParams {
     const double *P, *q, *G, *h, *A, *b;       // [B][n*n], [B][n], [B][m*n], [B][m], [B][p*n], [B][p]
+    long sP, sq, sG, sh, sA, sb;               // doubles between consecutive QPs (0: one array shared by all)
     double *x, *z, *y, *obj;                   // [B][n], [B][m], [B][p], [B]
     int *status, *iters;                       // [B]
     double* ws; long ws_stride;                // doubles per QP
@@ -214,12 +215,12 @@ __global__ __launch_bounds__(256) void dense_qp_kernel(DenseParams p) {
     __shared__ int sflag;
     const int tid = threadIdx.x, n = p.n, m = p.m, pe = p.p, mc = p.m + p.p, K = p.n;
     const int qi = blockIdx.x;
-    const double* P = p.P + (size_t)qi * n * n;
-    const double* q = p.q + (size_t)qi * n;
-    const double* G = p.G ? p.G + (size_t)qi * m * n : nullptr;
-    const double* h = p.h ? p.h + (size_t)qi * m : nullptr;
-    const double* A = p.A ? p.A + (size_t)qi * pe * n : nullptr;
-    const double* b = p.b ? p.b + (size_t)qi * pe : nullptr;
+    const double* P = p.P + (size_t)qi * p.sP;
+    const double* q = p.q + (size_t)qi * p.sq;
+    const double* G = p.G ? p.G + (size_t)qi * p.sG : nullptr;
+    const double* h = p.h ? p.h + (size_t)qi * p.sh : nullptr;
+    const double* A = p.A ? p.A + (size_t)qi * p.sA : nullptr;
+    const double* b = p.b ? p.b + (size_t)qi * p.sb : nullptr;
     Ws w;
     {
         double* c = p.ws + (size_t)qi * p.ws_stride;
@@ -493,15 +494,17 @@ long mpcqp_dense_workspace(int n, int m, int p, long* int_count) {
     return 4L * n * n + mc * n + 2L * n * n + 15L * V;
 }
 
-int mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const double* P, const double* q,
-                      const double* G, const double* h, const double* A, const double* b,
-                      double* x, double* z, double* y, double* obj, int* status, int* iters,
-                      double* workspace, int* int_workspace, void* stream) {
+int mpcqp_solve_dense_strided(int device_id, int batch, int n, int m, int p, const double* P, long sP, const double* q,
+                              long sq, const double* G, long sG, const double* h, long sh, const double* A, long sA,
+                              const double* b, long sb, double* x, double* z, double* y, double* obj, int* status,
+                              int* iters, double* workspace, int* int_workspace, void* stream) {
     if (batch < 1 || n < 1 || m < 0 || p < 0 || !P || !q || !x || !workspace || !int_workspace) return MPCQP_EINVAL;
     if ((m > 0 && (!G || !h)) || (p > 0 && (!A || !b))) return MPCQP_EINVAL;
+    if (sP < 0 || sq < 0 || sG < 0 || sh < 0 || sA < 0 || sb < 0) return MPCQP_EINVAL;
     if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
     DenseParams d;
     d.P = P; d.q = q; d.G = m ? G : nullptr; d.h = m ? h : nullptr; d.A = p ? A : nullptr; d.b = p ? b : nullptr;
+    d.sP = sP; d.sq = sq; d.sG = sG; d.sh = sh; d.sA = sA; d.sb = sb;
     d.x = x; d.z = z; d.y = y; d.obj = obj; d.status = status; d.iters = iters;
     long ic = 0;
     d.ws = workspace; d.ws_stride = mpcqp_dense_workspace(n, m, p, &ic);
@@ -510,6 +513,14 @@ int mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const doubl
     d.max_steps = 20 * (n + m + p) + 100; d.prox_iters = 30; d.refine = 2; d.sigma_rel = 1e-6;
     hipLaunchKernelGGL(dense_qp_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d);
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+int mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const double* P, const double* q,
+                      const double* G, const double* h, const double* A, const double* b,
+                      double* x, double* z, double* y, double* obj, int* status, int* iters,
+                      double* workspace, int* int_workspace, void* stream) {
+    return mpcqp_solve_dense_strided(device_id, batch, n, m, p, P, (long)n * n, q, n, G, (long)m * n, h, m, A, (long)p * n,
+                                     b, p, x, z, y, obj, status, iters, workspace, int_workspace, stream);
 }
 
 }  // extern "C"

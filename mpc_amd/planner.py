@@ -59,6 +59,8 @@ class Planner:
         self._dirty = True
         self.rho = None
         self.info = None
+        self._general = None         # state-box / polytopic rows, if any
+        self._gen = None             # their condensed form (G, E, h0), built by setup()
         self.no_sync = False         # True: set-up calls never wait for the device (closed loops)
         self.check_inputs = True     # False: skip the host-side sanity checks that synchronise (u_min <= u_max)
         self.opts = _lib.SolveOpts()
@@ -179,10 +181,31 @@ class Planner:
         self._check(self._lib.mpcqp_set_constraints(self._h, _ptr(k["u_min"]), _ptr(k["u_max"]), k["per_stage"]))
 
     def set_constraints(self, u_min, u_max, x_min=None, x_max=None, C=None, c_min=None, c_max=None):
-        """Input box u_min <= u_k <= u_max, (nu,) or (N,nu).  State boxes / polytopic rows are the
-        general-constraint path and are not implemented yet."""
-        if any(v is not None for v in (x_min, x_max, C, c_min, c_max)):
-            raise NotImplementedError("state-box / polytopic constraints are not implemented yet")
+        """Input box u_min <= u_k <= u_max, (nu,) or (N,nu).  State box x_min <= x_k <= x_max and polytopic rows
+        c_min <= C x_k <= c_max on x_1..x_N ((nx,)/(N,nx); C (nc,nx)/(N,nc,nx)) select the general-constraint path
+        (reference: state rows = rows of the prediction matrix,
+        LaunchPlannerQPFormulation.py:109-114, polytope rows Launch3DPlanner.py:134-142): the condensed QP then
+        has one constraint matrix [I; Gamma rows; C Gamma rows] for the whole batch and goes to the dense kernel."""
+        gen = {}
+        if x_min is not None or x_max is not None:
+            inf = torch.full((self.N, self.nx), float("inf"), dtype=torch.float64, device=self.device)
+            lo = -inf if x_min is None else _as_dev(x_min, self.device).expand(self.N, self.nx)
+            hi = inf if x_max is None else _as_dev(x_max, self.device).expand(self.N, self.nx)
+            gen["x_min"], gen["x_max"] = lo.contiguous(), hi.contiguous()
+        if C is not None:
+            Cm = _as_dev(C, self.device)
+            if Cm.dim() == 2:
+                Cm = Cm.unsqueeze(0).expand(self.N, -1, -1)
+            if Cm.dim() != 3 or Cm.shape[0] != self.N or Cm.shape[2] != self.nx:
+                raise ValueError(f"C: expected (nc, {self.nx}) or ({self.N}, nc, {self.nx})")
+            nc = Cm.shape[1]
+            inf = torch.full((self.N, nc), float("inf"), dtype=torch.float64, device=self.device)
+            gen["C"] = Cm.contiguous()
+            gen["c_min"] = (-inf if c_min is None else _as_dev(c_min, self.device).expand(self.N, nc)).contiguous()
+            gen["c_max"] = (inf if c_max is None else _as_dev(c_max, self.device).expand(self.N, nc)).contiguous()
+        elif c_min is not None or c_max is not None:
+            raise ValueError("c_min / c_max need C")
+        self._general = gen or None
         u_min = _as_dev(u_min, self.device); u_max = _as_dev(u_max, self.device)
         if tuple(u_min.shape) != tuple(u_max.shape):
             raise ValueError("u_min and u_max must have the same shape")
@@ -215,12 +238,60 @@ class Planner:
         if self._h is None or "Q" not in self._keep or "u_min" not in self._keep:
             raise RuntimeError("set_model, set_cost and set_constraints must be called before solve")
         self._check(self._lib.mpcqp_assemble(self._h, self._stream()))
+        if self._general:           # general rows: the dense kernel scales and factors per QP; no shared-factor set-up
+            self._gen = self._condense_rows()
+            self.rho = None
+            self._dirty = False
+            return self
+        self._gen = None
         no_sync = bool(self.no_sync and (self._n_models > 1 or rho))
         fo = _lib.FactorOpts(float(rho) if rho else 0.0, int(no_sync), int(bool(keep_state)))
         self._check(self._lib.mpcqp_factor(self._h, C.byref(fo), self._stream()))
         self.rho = (1.0 if self._n_models > 1 else float(rho)) if no_sync else float(self.get("rho")[0])
         self._dirty = False
         return self
+
+    def _condense_rows(self):
+        """One-sided rows G U <= h0 - E x0 of the condensed problem (rows with an infinite bound are dropped, as
+        HelperFuncs.removeNullConstraints does for the reference's stacked constraints)."""
+        if self._n_models != 1:
+            raise NotImplementedError("state / polytopic rows with one model per instance are not implemented")
+        n, nx, N = self.n, self.nx, self.N
+        dev = self.device
+        Gam = self.get("Gamma"); Phi = self.get("Phi")          # (N nx, n), (N nx, nx): x_k = Gam_k U + Phi_k x0
+        k = self._keep
+        ub = k["u_max"] if k["per_stage"] else k["u_max"].repeat(N)
+        lb = k["u_min"] if k["per_stage"] else k["u_min"].repeat(N)
+        I = torch.eye(n, dtype=torch.float64, device=dev)
+        Z = torch.zeros((n, nx), dtype=torch.float64, device=dev)
+        rows = [(I, Z, ub), (-I, Z, -lb)]
+        g = self._general
+        if "x_max" in g:
+            rows += [(Gam, Phi, g["x_max"].reshape(-1)), (-Gam, -Phi, -g["x_min"].reshape(-1))]
+        if "C" in g:
+            Cm = g["C"]                                            # (N, nc, nx)
+            CG = torch.bmm(Cm, Gam.reshape(N, nx, n)).reshape(-1, n)
+            CP = torch.bmm(Cm, Phi.reshape(N, nx, nx)).reshape(-1, nx)
+            rows += [(CG, CP, g["c_max"].reshape(-1)), (-CG, -CP, -g["c_min"].reshape(-1))]
+        G = torch.cat([r[0] for r in rows]); E = torch.cat([r[1] for r in rows]); h0 = torch.cat([r[2] for r in rows])
+        keep = torch.isfinite(h0)
+        return dict(G=G[keep].contiguous(), E=E[keep].contiguous(), h0=h0[keep].contiguous(),
+                    H=self.get("H"), F=self.get("F"), f0=self.get("f0"))
+
+    def _solve_general(self, x0, want_multipliers):
+        from . import solvers
+        gen = self._gen
+        q = torch.addmm(gen["f0"].unsqueeze(0), x0, gen["F"].t())          # q = F x0 + f0
+        h = gen["h0"].unsqueeze(0) - x0 @ gen["E"].t()                     # h = h0 - E x0
+        r = solvers.qp_batch(gen["H"], q, gen["G"], h, device=self.device)
+        B = x0.shape[0]
+        st = r["status"]
+        # dense status 0 optimal | 1 step cap | 2 infeasible | 3 numerical  ->  MPCQP_SOLVED | MPCQP_MAX_ITER | 3 | 4
+        status = torch.where(st == 0, torch.zeros_like(st), st + 1)
+        self.info = SimpleNamespace(iters=torch.zeros(B, dtype=torch.int32, device=self.device), status=status,
+                                    obj=r["obj"], prim_res=None, dual_res=None,
+                                    polish_steps=r["iters"] % 1000, lam=r["z"] if want_multipliers else None)
+        return r["x"].reshape(B, self.N, self.nu)
 
     def solve(self, x0, warm_start=None, want_multipliers=False, **opts):
         """x0 (B,nx) -> U (B,N,nu) on the device; per-instance diagnostics in ``self.info``
@@ -235,6 +306,8 @@ class Planner:
             x0 = x0.reshape(1, -1)
         if x0.dim() != 2 or x0.shape[1] != self.nx:
             raise ValueError(f"x0: expected (B, {self.nx}), got {tuple(x0.shape)}")
+        if self._gen is not None:
+            return self._solve_general(x0, want_multipliers)
         B = x0.shape[0]
         o = _lib.SolveOpts.from_buffer_copy(self.opts)
         for k, v in opts.items():

@@ -68,25 +68,28 @@ def _dev(a, dev):
 
 
 def qp_batch(P, q, G=None, h=None, A=None, b=None, device="cuda:0"):
-    """Batched form: P (B,n,n), q (B,n), G (B,m,n), h (B,m), A (B,p,n), b (B,p) as NumPy or torch.
-    Returns dict of torch tensors on the device: x (B,n), z (B,m), y (B,p), obj (B), status (B), iters (B)."""
+    """Batched form: q (B,n), h (B,m), b (B,p) per QP; P (B,n,n) | (n,n), G (B,m,n) | (m,n), A (B,p,n) | (p,n) per QP
+    or ONE matrix shared by the whole batch (the MPC case: one Hessian, one constraint matrix, per-instance q and h).
+    NumPy or torch.  Returns dict of torch tensors on the device: x (B,n), z (B,m), y (B,p), obj (B), status (B), iters (B)."""
     lib = _lib.load()
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("mpc_amd.solvers runs on a ROCm device only (no CPU path)")
     to = lambda a: None if a is None else (a.to(device=dev, dtype=torch.float64).contiguous() if torch.is_tensor(a) else _dev(a, dev))
     P, q, G, h, A, b = map(to, (P, q, G, h, A, b))
-    if P.dim() != 3 or P.shape[1] != P.shape[2]:
-        raise ValueError("P must be (B, n, n)")
-    B, n = P.shape[0], P.shape[1]
-    if tuple(q.shape) != (B, n):
+    if q.dim() != 2:
         raise ValueError("q must be (B, n)")
-    m = 0 if G is None else G.shape[1]
-    p = 0 if A is None else A.shape[1]
-    if m and (tuple(G.shape) != (B, m, n) or h is None or tuple(h.shape) != (B, m)):
-        raise ValueError("G must be (B, m, n) and h (B, m)")
-    if p and (tuple(A.shape) != (B, p, n) or b is None or tuple(b.shape) != (B, p)):
-        raise ValueError("A must be (B, p, n) and b (B, p)")
+    B, n = q.shape
+    if P.dim() not in (2, 3) or tuple(P.shape[-2:]) != (n, n) or (P.dim() == 3 and P.shape[0] != B):
+        raise ValueError("P must be (B, n, n) or (n, n)")
+    m = 0 if G is None else G.shape[-2]
+    p = 0 if A is None else A.shape[-2]
+    if m and (G.dim() not in (2, 3) or G.shape[-1] != n or (G.dim() == 3 and G.shape[0] != B)
+              or h is None or tuple(h.shape) != (B, m)):
+        raise ValueError("G must be (B, m, n) or (m, n) and h (B, m)")
+    if p and (A.dim() not in (2, 3) or A.shape[-1] != n or (A.dim() == 3 and A.shape[0] != B)
+              or b is None or tuple(b.shape) != (B, p)):
+        raise ValueError("A must be (B, p, n) or (p, n) and b (B, p)")
     x = torch.empty((B, n), dtype=torch.float64, device=dev)
     z = torch.zeros((B, max(m, 1)), dtype=torch.float64, device=dev)
     y = torch.zeros((B, max(p, 1)), dtype=torch.float64, device=dev)
@@ -98,9 +101,11 @@ def qp_batch(P, q, G=None, h=None, A=None, b=None, device="cuda:0"):
     ws = torch.empty(B * nd, dtype=torch.float64, device=dev)
     iws = torch.empty(B * ni.value, dtype=torch.int32, device=dev)
     ptr = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
-    rc = lib.mpcqp_solve_dense(dev.index or 0, B, n, m, p, ptr(P), ptr(q), ptr(G), ptr(h), ptr(A), ptr(b),
-                               ptr(x), ptr(z), ptr(y), ptr(obj), ptr(status), ptr(iters), ptr(ws), ptr(iws),
-                               C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    stride = lambda t, per: 0 if (t is None or t.dim() == 2) else per
+    rc = lib.mpcqp_solve_dense_strided(dev.index or 0, B, n, m, p, ptr(P), stride(P, n * n), ptr(q), n,
+                                       ptr(G), stride(G, m * n), ptr(h), m, ptr(A), stride(A, p * n), ptr(b), p,
+                                       ptr(x), ptr(z), ptr(y), ptr(obj), ptr(status), ptr(iters), ptr(ws), ptr(iws),
+                                       C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
     if rc == _lib.EINVAL:
         raise ValueError("mpcqp_solve_dense: invalid argument")
     if rc != _lib.OK:
