@@ -104,7 +104,7 @@ def long_horizon(batch=256, seed=0, N=100, nx=20, nu=6):
     Q = np.eye(nx); R = 0.1 * np.eye(nu)
     P = sl.solve_discrete_are(A, B, Q, R)
     C = rng.standard_normal((2 * nx, nx)) / np.sqrt(nx)
-    x0 = rng.uniform(-1.0, 1.0, (batch, nx))
+    x0 = rng.uniform(-0.6, 0.6, (batch, nx))
     return dict(name="long_horizon", nx=nx, nu=nu, N=N, A=A, B=B, Q=Q, R=R, P=P, u_min=-0.5 * np.ones(nu),
                 u_max=0.5 * np.ones(nu), x_min=-1.2 * np.ones(nx), x_max=1.2 * np.ones(nx), C=C,
                 c_min=-1.0 * np.ones(2 * nx), c_max=1.0 * np.ones(2 * nx), x0=x0)

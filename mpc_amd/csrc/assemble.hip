@@ -18,6 +18,7 @@ namespace {
 
 struct AsmParams {
     const double *A, *B, *Q, *R, *P, *xref, *uref;
+    int rows_in_lds;
     long xref_stride, uref_stride;       // doubles between the references of consecutive models (0: shared)
     double *Gam, *QG, *Phi, *H, *F, *f0;
     int nx, nu, N, n, p, tv;
@@ -37,20 +38,22 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     double* F = a.F + (size_t)m * n * nx;
     double* f0 = a.f0 + (size_t)m * n;
 
-    double* rowG = reinterpret_cast<double*>(smem);     // 2 x (nx, n) ping-pong
-    double* rowP = rowG + 2 * nx * n;                   // 2 x (nx, nx)
+    // row-block buffers of the rollout: LDS ping-pong, or (long horizons, a.rows_in_lds == 0) the rows of Gamma
+    // themselves in global memory -- block k-1 is complete and visible to the workgroup when block k reads it
+    double* rowP = reinterpret_cast<double*>(smem);     // 2 x (nx, nx)
+    double* rowG = rowP + 2 * nx * nx;                  // 2 x (nx, n) ping-pong
     const int tid = threadIdx.x;
 
     // ---- phase 1: rollout --------------------------------------------------------------
-    for (int i = tid; i < nx * n; i += 256) rowG[i] = 0.0;
+    if (a.rows_in_lds) for (int i = tid; i < nx * n; i += 256) rowG[i] = 0.0;
     for (int i = tid; i < nx * nx; i += 256) rowP[i] = (i / nx == i % nx) ? 1.0 : 0.0;
     __syncthreads();
     for (int k = 0; k < N; ++k) {
         const double* Ak = Am + (a.tv ? (size_t)k * nx * nx : 0);
         const double* Bk = Bm + (a.tv ? (size_t)k * nx * nu : 0);
         const double* Qk = (k == N - 1) ? a.P : a.Q;
-        const double* gin = rowG + (k & 1) * nx * n;
-        double* gout = rowG + ((k + 1) & 1) * nx * n;
+        const double* gin = a.rows_in_lds ? rowG + (k & 1) * nx * n : Gam + (size_t)(k > 0 ? k - 1 : 0) * nx * n;
+        double* gout = a.rows_in_lds ? rowG + ((k + 1) & 1) * nx * n : Gam + (size_t)k * nx * n;
         const double* pin = rowP + (k & 1) * nx * nx;
         double* pout = rowP + ((k + 1) & 1) * nx * nx;
         for (int i = tid; i < nx * n; i += 256) {
@@ -63,7 +66,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
                 s = Bk[r * nu + (c - k * nu)];
             }
             gout[i] = s;
-            Gam[(size_t)(k * nx + r) * n + c] = s;
+            if (a.rows_in_lds) Gam[(size_t)(k * nx + r) * n + c] = s;
         }
         for (int i = tid; i < nx * nx; i += 256) {
             const int r = i / nx, c = i % nx;
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
             pout[i] = s;
             Phi[(size_t)(k * nx + r) * nx + c] = s;
         }
+        __threadfence_block();
         __syncthreads();
         for (int i = tid; i < nx * n; i += 256) {
             const int r = i / n, c = i % n;
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
             for (int j = 0; j < nx; ++j) s += Qk[r * nx + j] * gout[j * n + c];
             QG[(size_t)(k * nx + r) * n + c] = s;
         }
+        __threadfence_block();
         __syncthreads();
     }
     __threadfence_block();
@@ -162,8 +167,10 @@ int launch_assemble(mpcqp_handle h, hipStream_t st) {
     a.xref_stride = h->xref_stride; a.uref_stride = h->uref_stride;
     a.Gam = h->Gam; a.QG = h->QG; a.Phi = h->Phi; a.H = h->H; a.F = h->F; a.f0 = h->f0;
     a.nx = h->dims.nx; a.nu = h->dims.nu; a.N = h->dims.N; a.n = h->n; a.p = h->p; a.tv = h->dims.time_varying;
-    const size_t lds = (size_t)(2 * a.nx * a.n + 2 * a.nx * a.nx) * sizeof(double);
-    if (lds > 160 * 1024) { h->err = "assemble: nx*N*nu too large for the LDS row buffers"; return MPCQP_ENOTIMPL; }
+    size_t lds = (size_t)(2 * a.nx * a.n + 2 * a.nx * a.nx) * sizeof(double);
+    a.rows_in_lds = lds <= 160 * 1024;
+    if (!a.rows_in_lds) lds = (size_t)(2 * a.nx * a.nx) * sizeof(double);
+    if (lds > 160 * 1024) { h->err = "assemble: nx too large for the LDS buffers"; return MPCQP_ENOTIMPL; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return MPCQP_EHIP; }

@@ -238,7 +238,8 @@ class Planner:
         if self._h is None or "Q" not in self._keep or "u_min" not in self._keep:
             raise RuntimeError("set_model, set_cost and set_constraints must be called before solve")
         self._check(self._lib.mpcqp_assemble(self._h, self._stream()))
-        if self._general:           # general rows: the dense kernel scales and factors per QP; no shared-factor set-up
+        if self._general is not None or (self._n_models == 1 and self.n > 128):
+            # general rows (or a horizon beyond the ADMM kernel's n <= 128): the dense kernel scales and factors per QP
             self._gen = self._condense_rows()
             self.rho = None
             self._dirty = False
@@ -265,7 +266,7 @@ class Planner:
         I = torch.eye(n, dtype=torch.float64, device=dev)
         Z = torch.zeros((n, nx), dtype=torch.float64, device=dev)
         rows = [(I, Z, ub), (-I, Z, -lb)]
-        g = self._general
+        g = self._general or {}
         if "x_max" in g:
             rows += [(Gam, Phi, g["x_max"].reshape(-1)), (-Gam, -Phi, -g["x_min"].reshape(-1))]
         if "C" in g:

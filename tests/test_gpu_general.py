@@ -33,6 +33,7 @@ def test_state_and_polytope_rows_match_oracle(N, nx, nu, batch):
     from oracle import mpc_oracle as mo
     from oracle.qp_oracle import solve_qp
     prob = long_horizon(batch=batch, seed=3, N=N, nx=nx, nu=nu)
+    prob["x0"] *= 1.6                     # far enough out that state and polytope rows bind (some instances infeasible)
     prob["x_max"][0] = np.inf            # a dropped (null) row block
     pl = Planner(nx, nu, N).set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
     pl.set_constraints(prob["u_min"], prob["u_max"], x_min=prob["x_min"], x_max=prob["x_max"],
@@ -56,3 +57,32 @@ def test_state_and_polytope_rows_match_oracle(N, nx, nu, batch):
         assert (G @ U[i] - h <= 1e-9 * max(1.0, np.abs(h).max())).all()
         nbind += int((np.abs(G @ s["x"] - h) < 1e-8)[2 * N * nu:].sum())
     assert nbind > 0                     # state / polytope rows do bind somewhere in the batch
+
+
+def test_full_horizon_config5_kkt_certificate():
+    """BASELINE.json configs[4] at its full size (nx=20, nu=6, N=100: n=600, 13,200 one-sided rows): too large for the
+    oracle to finish in seconds, so parity is the solver-independent KKT certificate on every instance."""
+    from mpc_amd.configs import long_horizon
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    batch = 8
+    prob = long_horizon(batch=batch, seed=1)
+    prob["x0"] *= 1.3
+    pl = Planner(prob["nx"], prob["nu"], prob["N"]).set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+    pl.set_constraints(prob["u_min"], prob["u_max"], x_min=prob["x_min"], x_max=prob["x_max"],
+                       C=prob["C"], c_min=prob["c_min"], c_max=prob["c_max"])
+    U = pl.solve(prob["x0"], want_multipliers=True).cpu().numpy().reshape(batch, -1)
+    st = pl.info.status.cpu().numpy(); z = pl.info.lam.cpu().numpy(); obj = pl.info.obj.cpu().numpy()
+    H, F, f0 = mo.condense(prob)
+    G, E, h0 = _oracle_rows(prob)
+    assert z.shape[1] == G.shape[0] == 13200
+    assert (st == 0).sum() >= batch // 2
+    for i in np.nonzero(st == 0)[0]:
+        q = F @ prob["x0"][i] + f0; h = h0 - E @ prob["x0"][i]
+        scale = max(1.0, np.abs(q).max())
+        assert np.abs(H @ U[i] + q + G.T @ z[i]).max() <= 1e-8 * scale          # stationarity
+        assert (G @ U[i] - h).max() <= 1e-9 * max(1.0, np.abs(h).max())          # primal feasibility
+        assert z[i].min() >= 0.0                                                  # dual feasibility
+        assert abs(z[i] @ (G @ U[i] - h)) <= 1e-8 * scale                         # complementarity
+        assert abs(obj[i] - (0.5 * U[i] @ H @ U[i] + q @ U[i])) <= 1e-8 * max(1.0, abs(obj[i]))
+        assert (z[i] > 0).sum() > 0

@@ -183,12 +183,30 @@ def test_error_conventions():
         pl.solve(np.zeros((1, 2)))
     with pytest.raises(ValueError):
         pl.set_cost(np.eye(3), np.eye(1))
-    with pytest.raises(NotImplementedError):
-        pl.set_constraints([-1.0], [1.0], x_min=[0, 0])
-    big = Planner(2, 2, 100)                        # N*nu = 200 > 128
-    big.set_model(np.eye(2), np.eye(2)).set_cost(np.eye(2), np.eye(2)).set_constraints([-1, -1], [1, 1])
-    with pytest.raises(NotImplementedError):
-        big.solve(np.zeros((1, 2)))
+    with pytest.raises(ValueError):
+        pl.set_constraints([-1.0], [1.0], c_min=[0.0])      # polytope bounds without C
+    with pytest.raises(NotImplementedError):              # state rows with one model per instance
+        pm = Planner(2, 1, 5).set_model(np.tile(np.eye(2), (3, 1, 1, 1)), np.ones((3, 1, 2, 1)))
+        pm.set_cost(np.eye(2), np.eye(1)).set_constraints([-1.0], [1.0], x_min=[0, 0])
+        pm.solve(np.zeros((3, 2)))
+
+
+def test_horizon_beyond_128_inputs_goes_to_the_dense_kernel():
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_box_qp
+    rng = np.random.default_rng(4)
+    A = np.array([[1.0, 0.1], [0.0, 1.0]]); B = np.array([[0.005, 0.0], [0.1, 0.02]])
+    big = Planner(2, 2, 70)                         # N*nu = 140 > 128
+    big.set_model(A, B).set_cost(np.eye(2), 0.1 * np.eye(2)).set_constraints([-0.3, -1], [0.3, 1])
+    x0 = rng.uniform(-3, 3, (6, 2))
+    U = big.solve(x0).cpu().numpy().reshape(6, -1)
+    assert (big.info.status.cpu().numpy() == 0).all()
+    prob = dict(N=70, nx=2, nu=2, A=A, B=B, Q=np.eye(2), R=0.1 * np.eye(2), P=np.eye(2))
+    H, F, f0 = mo.condense(prob)
+    for i in range(6):
+        s = solve_box_qp(H, F @ x0[i] + f0, np.tile([-0.3, -1.0], 70), np.tile([0.3, 1.0], 70))
+        assert np.abs(U[i] - s["x"]).max() <= 1e-6 * max(1.0, np.abs(s["x"]).max())
 
 
 def test_ragged_and_tiny_batches():
