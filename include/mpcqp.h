@@ -129,6 +129,11 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U,
 /* receding horizon: shift the kept (z, w) one stage forward, repeating the last stage */
 int mpcqp_shift(mpcqp_handle h, void* stream);
 
+/* trajectory recovery (`x_traj = Gamma u* + ...`, LaunchPlannerQPFormulation.py:176-183, Launch3DPlanner.py:202-211):
+ * X (batch, N, nx) = x_1..x_N of x_{k+1} = A_k x_k + B_k u_k from x0 (batch, nx) and U (batch, N*nu), each instance
+ * with the model the handle holds for it */
+int mpcqp_predict(mpcqp_handle h, const double* x0, const double* U, int batch, double* X, void* stream);
+
 /* deviation-form re-linearisation (the reference's `D = D + optX` / `f += delf` pattern, CollocationBasedPlanner2D.py:363,
  * SE3Planner.py:194-195): when the next QP is posed in increments about the shifted previous plan, the kept primal
  * state is zeroed (the plan itself is the new origin) while the kept multipliers still mark the active bounds */

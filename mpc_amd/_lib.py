@@ -51,6 +51,7 @@ SYMBOLS = [
     ("mpcqp_solve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Info),
                               C.POINTER(SolveOpts), C.c_void_p]),
     ("mpcqp_shift", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mpcqp_predict", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("mpcqp_recenter", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_get", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),

@@ -337,6 +337,21 @@ class Planner:
         self._check(self._lib.mpcqp_shift(self._h, self._stream()))
         return self
 
+    def predict(self, x0, U):
+        """States x_1..x_N (B, N, nx) that the inputs U (B, N, nu) produce from x0 (B, nx) under the model(s) set
+        with set_model -- the reference's `x_traj = Gamma u* + ...` read-back (LaunchPlannerQPFormulation.py:176-183)."""
+        if self._h is None:
+            raise RuntimeError("set_model must be called before predict")
+        x0 = _as_dev(x0, self.device); U = _as_dev(U, self.device)
+        if x0.dim() == 1:
+            x0 = x0.reshape(1, -1)
+        B = x0.shape[0]
+        if x0.shape[1] != self.nx or U.numel() != B * self.n:
+            raise ValueError(f"predict: expected x0 (B, {self.nx}) and U (B, {self.N}, {self.nu})")
+        X = torch.empty((B, self.N, self.nx), dtype=torch.float64, device=self.device)
+        self._check(self._lib.mpcqp_predict(self._h, _ptr(x0), _ptr(U.reshape(B, -1).contiguous()), B, _ptr(X), self._stream()))
+        return X
+
     def recenter(self):
         """Deviation-form re-linearisation: zero the kept primal state (the shifted plan becomes the origin of
         the next QP), keep the multipliers as the active-set guess."""

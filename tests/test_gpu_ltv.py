@@ -50,6 +50,13 @@ def test_per_instance_models_match_oracle():
         assert ((lam[i] != 0) == act).all() or _rel(U[i], s["x"]) <= 1e-10
         nact += act.sum()
     assert nact > Bn            # the bounds do bind in this test
+    # trajectory recovery with one (time-varying) model per instance
+    X = pl.predict(x0, U).cpu().numpy()
+    for i in (0, 5, 23):
+        xk = x0[i].copy()
+        for k in range(N):
+            xk = A[i, k] @ xk + Bm[i, k] @ U[i].reshape(N, nu)[k]
+            assert np.abs(X[i, k] - xk).max() <= 1e-12 * max(1.0, np.abs(xk).max())
     # per-instance LTI (stage dimension 1) takes the same path
     pl2 = Planner(nx, nu, N).set_model(A[:, :1], Bm[:, :1]).set_cost(Q, R, P).set_constraints(lb[0, 0], ub[0, 0])
     U2 = pl2.solve(x0).cpu().numpy().reshape(Bn, -1)

@@ -217,3 +217,17 @@ def test_ragged_and_tiny_batches():
     for b in (1, 15, 17, 63, 65):
         Ub = pl.solve(prob["x0"][:b]).cpu().numpy()
         assert np.abs(Ub - Uall[:b]).max() <= 1e-9 * np.abs(Uall).max(), b
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3])
+def test_predict_matches_prediction_matrices(cfg):
+    """x_traj = Gamma u* + Phi x0 (LaunchPlannerQPFormulation.py:176-183) without forming Gamma on the device."""
+    from mpc_amd.configs import make_config
+    from oracle.mpc_oracle import rollout_matrices
+    prob = make_config(cfg, batch=37, seed=9)
+    pl = _planner(prob)
+    U = pl.solve(prob["x0"])
+    X = pl.predict(prob["x0"], U).cpu().numpy().reshape(37, -1)
+    Gam, Phi = rollout_matrices(prob["A"], prob["B"], prob["N"])
+    Xo = U.cpu().numpy().reshape(37, -1) @ Gam.T + prob["x0"] @ Phi.T
+    assert np.abs(X - Xo).max() <= 1e-12 * max(1.0, np.abs(Xo).max())
