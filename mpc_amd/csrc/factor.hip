@@ -268,6 +268,153 @@ __global__ __launch_bounds__(256) void factor_batch_kernel(FacBatchParams f) {
     }
 }
 
+// n <= 64: one WAVE per model, lane i owns row i, no workgroup barriers (the 256-thread kernel above spends its
+// time in ~200 barriers per model).  LDS per wave: L, L^-1, Hi, each n x (n+1).
+__device__ __forceinline__ void wv_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int n = f.n, nx = f.nx, nx1 = f.nx + 1, NP = f.NP, i = threadIdx.x, LDW = n + 1;
+    const size_t m = blockIdx.x;
+    const double* __restrict__ H = f.H + m * n * n;
+    const double* __restrict__ F = f.F + m * n * nx;
+    const double* __restrict__ f0 = f.f0 + m * n;
+    double* __restrict__ gHs = f.Hs + m * n * n;
+    double* __restrict__ gHi = f.Hi + m * n * n;
+    double* sL = reinterpret_cast<double*>(smem);        // lower Cholesky factor of Hs (upper part: Hs itself)
+    double* sT = sL + (size_t)n * LDW;                    // L^-1
+    double* sHi = sL;                                     // Hs^-1 (overwrites L, dead once L^-1 exists)
+    double* sd = sT + (size_t)n * LDW;                    // d
+    const bool in = i < n;
+    bool bad = false;
+    double di = 1.0;
+    if (in) {
+        const double hii = H[(size_t)i * n + i];
+        if (!(hii > 0.0)) bad = true; else di = 1.0 / sqrt(hii);
+        sd[i] = di;
+    }
+    wv_sync();
+    // Hs = d H d (symmetrised), row i: coalesced over j by looping rows and letting lanes take columns
+    // (stage H through LDS with coalesced loads only, then symmetrise from LDS)
+#pragma unroll 8
+    for (int r = 0; r < n; ++r) if (in) sT[r * LDW + i] = H[(size_t)r * n + i];
+    wv_sync();
+    for (int r = 0; r < n; ++r)
+        if (in) {
+            const double v = 0.5 * (sT[r * LDW + i] + sT[i * LDW + r]) * sd[r] * di;
+            sL[r * LDW + i] = v;
+            gHs[(size_t)r * n + i] = v;
+        }
+    wv_sync();
+    // left-looking Cholesky: column j from columns < j
+    for (int j = 0; j < n; ++j) {
+        double v = 0.0;
+        if (in && i >= j) {
+            v = sL[i * LDW + j];
+#pragma unroll 4
+            for (int k = 0; k < j; ++k) v -= sL[i * LDW + k] * sL[j * LDW + k];
+        }
+        const double piv = __shfl(v, j, 64);
+        if (!(piv > 0.0)) { bad = true; }
+        const double rs = (piv > 0.0) ? 1.0 / sqrt(piv) : 1.0;
+        wv_sync();
+        if (in && i >= j) sL[i * LDW + j] = (i == j) ? piv * rs : v * rs;
+        wv_sync();
+    }
+    // T = L^-1, lane c computes column c
+    if (in) {
+        const int c = i;
+        for (int r = c; r < n; ++r) {
+            double sacc = (r == c) ? 1.0 : 0.0;
+#pragma unroll 4
+            for (int k = c; k < r; ++k) sacc -= sL[r * LDW + k] * sT[k * LDW + c];
+            sT[r * LDW + c] = sacc / sL[r * LDW + r];
+        }
+        for (int r = 0; r < c; ++r) sT[r * LDW + c] = 0.0;
+    }
+    wv_sync();
+    // Hi = T'T, lane i computes row i
+    if (in)
+        for (int j = 0; j < n; ++j) {
+            double sacc = 0.0;
+#pragma unroll 4
+            for (int k = (i > j ? i : j); k < n; ++k) sacc += sT[k * LDW + i] * sT[k * LDW + j];
+            sHi[i * LDW + j] = sacc;
+        }
+    wv_sync();
+    for (int r = 0; r < n; ++r) if (in) gHi[(size_t)r * n + i] = sHi[r * LDW + i];
+    // [Fs | f0s] and [Ku | ku], also transposed (nx+1, NP)
+    double* __restrict__ Fs1 = f.Fs1 + m * n * nx1;
+    double* __restrict__ Ku1 = f.Ku1 + m * n * nx1;
+    double* __restrict__ FsT = f.FsT + m * NP * nx1;
+    double* __restrict__ KuT = f.KuT + m * NP * nx1;
+    double* sF = sT;                                      // reuse: (n, nx1)
+    wv_sync();
+    if (in)
+        for (int c = 0; c < nx1; ++c) {
+            const double v = di * (c < nx ? F[(size_t)i * nx + c] : f0[i]);
+            sF[i * nx1 + c] = v; Fs1[(size_t)i * nx1 + c] = v;
+        }
+    wv_sync();
+    for (int c = 0; c < nx1; ++c) {
+        double su = 0.0;
+        if (in) {
+#pragma unroll 4
+            for (int k = 0; k < n; ++k) su -= sHi[i * LDW + k] * sF[k * nx1 + c];
+        }
+        if (in) Ku1[(size_t)i * nx1 + c] = su;
+        for (int r = i; r < NP; r += 64) {
+            FsT[c * NP + r] = r < n ? sF[r * nx1 + c] : 0.0;
+            if (r >= n) KuT[c * NP + r] = 0.0;
+        }
+        if (in) KuT[c * NP + i] = su;
+    }
+    // accuracy of the explicit inverse, estimated with two probe vectors instead of the full n^2 product (this
+    // kernel is instruction bound): max_i |(Hs Hi v - v)_i| for v = ones and v = (+1,-1,...); it only decides
+    // whether the solve refines with Hs itself
+    double e = 0.0;
+    {
+        double v1 = 0.0, v2 = 0.0;
+        if (in) {
+#pragma unroll 4
+            for (int j = 0; j < n; ++j) { const double hv = sHi[i * LDW + j]; v1 += hv; v2 += (j & 1) ? -hv : hv; }
+        }
+        wv_sync();
+        double* p1 = sT;                      // L^-1 is dead: reuse two of its rows
+        double* p2 = sT + LDW;
+        if (in) { p1[i] = v1; p2[i] = v2; }
+        wv_sync();
+        if (in) {
+            double w1 = 0.0, w2 = 0.0;
+#pragma unroll 4
+            for (int k = 0; k < n; ++k) { const double hs = gHs[(size_t)k * n + i]; w1 += hs * p1[k]; w2 += hs * p2[k]; }
+            e = fmax(fabs(w1 - 1.0), fabs(w2 - ((i & 1) ? -1.0 : 1.0)));
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) e = fmax(e, __shfl_xor(e, off, 64));
+    const bool anybad = __any(bad);
+    if (i == 0) {
+        atomicMax(reinterpret_cast<unsigned long long*>(f.rho_dev + 3), (unsigned long long)__double_as_longlong(e));
+        if (anybad) atomicOr(f.flag, 1);
+        f.mflag[m] = anybad ? 1 : 0;
+    }
+    const double* umin = f.umin + m * f.bnd_stride;
+    const double* umax = f.umax + m * f.bnd_stride;
+    for (int r = i; r < NP; r += 64) {
+        double lo = 0.0, hi = 0.0;
+        if (r < n) {
+            const int j = f.per_stage ? r : (r % f.nu);
+            lo = umin[j] / sd[r];
+            hi = umax[j] / sd[r];
+        }
+        f.lbs[m * NP + r] = lo; f.ubs[m * NP + r] = hi;
+    }
+    if (in) f.d[m * n + i] = di;
+}
+
 }  // namespace
 
 int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
@@ -299,6 +446,12 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st) {
     if (e == hipSuccess && f.use_lds)
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
+    if (h->n <= 64) {       // one wave per model
+        const size_t wl = ((size_t)2 * h->n * (h->n + 1) + h->n) * sizeof(double);
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+        if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
+        hipLaunchKernelGGL(factor_wave_kernel, dim3(h->dims.n_models), dim3(64), wl, st, f);
+    } else
     hipLaunchKernelGGL(factor_batch_kernel, dim3(h->dims.n_models), dim3(256), f.use_lds ? lds : 0, st, f);
     e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("factor (batch) launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
