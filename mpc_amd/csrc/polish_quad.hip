@@ -133,6 +133,31 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     const bool valid = slot0 + li < total;
     const int inst = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
 
+    // the ADMM iterate (z, w) of my rows: issued first so that the HBM latency hides behind the staging below
+    double zz[RPL], ww[RPL];
+#pragma unroll
+    for (int j = 0; j < RPL; ++j) { zz[j] = 0.0; ww[j] = 0.0; }
+    double* zb = p.z + (size_t)inst * p.NP;
+    double* wb = p.w + (size_t)inst * p.NP;
+    if (valid) {
+        if (!(n & 1)) {     // pairs never straddle n: 16-byte loads
+#pragma unroll
+            for (int jj = 0; jj < RP; ++jj) {
+                const int row = ROWJ(2 * jj);
+                double2 a = make_double2(0.0, 0.0), b = a;
+                if (row < n) { a = *reinterpret_cast<const double2*>(zb + row); b = *reinterpret_cast<const double2*>(wb + row); }
+                zz[2 * jj] = a.x; zz[2 * jj + 1] = a.y; ww[2 * jj] = b.x; ww[2 * jj + 1] = b.y;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int row = ROWJ(j);
+                zz[j] = (row < n) ? zb[row] : 0.0;
+                ww[j] = (row < n) ? wb[row] : 0.0;
+            }
+        }
+    }
+
     // ---- stage the shared data --------------------------------------------------------------
     {   // Hi -> LDS, six rows in flight per thread (n <= 128 columns: one column per thread of a 128-group)
         constexpr int TR = THREADS / 128;
@@ -192,26 +217,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 
     // ---- active-set guess from the ADMM iterate (z at a bound and the scaled dual pushing outwards) ---
     unsigned mU = 0u, mL = 0u;
-    double* zb = p.z + (size_t)inst * p.NP;
-    double* wb = p.w + (size_t)inst * p.NP;
     if (valid) {
-        double zz[RPL], ww[RPL];
-        if (!(n & 1)) {     // pairs never straddle n: 16-byte loads
-#pragma unroll
-            for (int jj = 0; jj < RP; ++jj) {
-                const int row = ROWJ(2 * jj);
-                double2 a = make_double2(0.0, 0.0), b = a;
-                if (row < n) { a = *reinterpret_cast<const double2*>(zb + row); b = *reinterpret_cast<const double2*>(wb + row); }
-                zz[2 * jj] = a.x; zz[2 * jj + 1] = a.y; ww[2 * jj] = b.x; ww[2 * jj + 1] = b.y;
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < RPL; ++j) {
-                const int row = ROWJ(j);
-                zz[j] = (row < n) ? zb[row] : 0.0;
-                ww[j] = (row < n) ? wb[row] : 0.0;
-            }
-        }
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int row = ROWJ(j);
