@@ -31,6 +31,7 @@ struct AdmmParams {
     double* prim;           // [B]
     double* dual;           // [B]
     int B, nx, SX;
+    int k_in_lds;           // 1: Kbfrag, Kufrag are staged behind M in LDS
     int max_iter, min_iter, check_every, warm, stop_on_stable;
     double eps_abs, eps_rel, alpha, rho;
 };
@@ -175,8 +176,18 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
         double2* dst = reinterpret_cast<double2*>(sM);
         for (int i = threadIdx.x; i < NT * S * 32; i += 256) dst[i] = src[i];
         for (int i = threadIdx.x; i < NP; i += 256) sB[i] = double2{p.lbs[i], p.ubs[i]};
+        if (p.k_in_lds) {   // the two prologue maps too: 2 x NT*SX fragments behind M (one bulk copy instead of
+                            // 2 NT SX dependent L2 round trips per wave)
+            const double2* ks = reinterpret_cast<const double2*>(p.Kbfrag);
+            const double2* us = reinterpret_cast<const double2*>(p.Kufrag);
+            double2* kd = reinterpret_cast<double2*>(sM + NT * S * 64);
+            const int cnt = NT * p.SX * 32;
+            for (int i = threadIdx.x; i < cnt; i += 256) { kd[i] = ks[i]; kd[cnt + i] = us[i]; }
+        }
     }
     __syncthreads();
+    const double* Kb = p.k_in_lds ? sM + NT * S * 64 : p.Kbfrag;
+    const double* Ku = p.k_in_lds ? sM + NT * S * 64 + NT * p.SX * 64 : p.Kufrag;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -208,7 +219,7 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
         d4 acc = {0, 0, 0, 0};
 #pragma unroll
         for (int s = 0; s < SXMAX; ++s)
-            if (s < p.SX) acc = mfma_f64(p.Kbfrag[(size_t)(t * p.SX + s) * 64 + lane], xf[s], acc);
+            if (s < p.SX) acc = mfma_f64(Kb[(t * p.SX + s) * 64 + lane], xf[s], acc);
 #pragma unroll
         for (int q = 0; q < 4; ++q) b0p[(t * 4 + q) * 64 + lane] = acc[q];
     }
@@ -231,7 +242,7 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
             d4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < SXMAX; ++s)
-                if (s < p.SX) acc = mfma_f64(p.Kufrag[(size_t)(t * p.SX + s) * 64 + lane], xf[s], acc);
+                if (s < p.SX) acc = mfma_f64(Ku[(t * p.SX + s) * 64 + lane], xf[s], acc);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int row = 16 * t + 4 * r + kq;
@@ -319,17 +330,21 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
 
 template <int NT, int S>
 int launch_one(const AdmmParams& p, hipStream_t st) {
-    const size_t lds = (size_t)(NT * S * 64 + 2 * 16 * NT) * sizeof(double);
-    static bool attr_set = false;
-    if (!attr_set) {
+    size_t lds = (size_t)(NT * S * 64 + 2 * 16 * NT) * sizeof(double);
+    const size_t klds = (size_t)2 * NT * p.SX * 64 * sizeof(double);
+    AdmmParams q = p;
+    q.k_in_lds = (lds + klds <= 160 * 1024) ? 1 : 0;
+    if (q.k_in_lds) lds += klds;
+    static size_t attr_set = 0;
+    if (attr_set < lds) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&admm_shared_box_kernel<NT, S>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        attr_set = true;
+        attr_set = lds;
     }
     const int nblk16 = ceil_div(p.B, 16);
     const int grid = ceil_div(nblk16, 4);
-    hipLaunchKernelGGL((admm_shared_box_kernel<NT, S>), dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL((admm_shared_box_kernel<NT, S>), dim3(grid), dim3(256), lds, st, q);
     return (int)hipGetLastError();
 }
 
