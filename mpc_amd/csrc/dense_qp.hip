@@ -363,7 +363,7 @@ __global__ __launch_bounds__(256) void dense_qp_kernel(DenseParams p) {
                 for (int a = tid; a < k; a += 256) { part += w.lv[a] * w.lv[a]; w.rv[a] = w.lv[a]; }
                 const double d2 = nHn - wg_sum(part, red);
                 wg_trsv(w.L, n, k, w.rv, false, true);
-                const bool dep = !(d2 > 1e-11 * nHn);
+                const bool dep = !(d2 > 1e-13 * nHn);
                 const double t2 = dep ? 1e300 : v0 / d2;
                 double t1 = 1e300; int jb = -1;
                 for (int a = tid; a < k; a += 256)

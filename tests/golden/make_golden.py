@@ -164,9 +164,88 @@ def make_mpc_fixtures():
               f"active min/max={int((lam != 0).sum(1).min())}/{int((lam != 0).sum(1).max())}")
 
 
+def _install_solving_recorder(log, every):
+    """Like the recorder above, but ``solvers.qp`` answers with the oracle's certified optimum so that the script's
+    sequential-QP loop keeps running on its own data; every ``every``-th call is logged."""
+    from oracle.qp_oracle import solve_qp
+    _install_recorder({})
+    sol = sys.modules["cvxopt.solvers"]
+    count = [0]
+
+    def qp(P, q, G=None, h=None, A=None, b=None, *a, **k):
+        args = [None if v is None else np.array(v, dtype=float) for v in (P, q, G, h, A, b)]
+        s = solve_qp(*args)
+        if count[0] % every == 0:
+            log.append(dict(call=count[0], args=args, x=s["x"], z=s["z"], y=s["y"], obj=s["primal objective"],
+                            kkt=s["kkt"]["max"], status=s["status"]))
+        count[0] += 1
+        n = args[1].size
+        return {"x": np.asarray(s["x"], float).reshape(n, 1), "status": s["status"], "z": s["z"], "y": s["y"],
+                "primal objective": s["primal objective"]}
+
+    sol.qp = qp
+    return count
+
+
+def run_sweep(script, every):
+    log = []
+    count = _install_solving_recorder(log, every)
+    os.environ["MPLBACKEND"] = "Agg"
+    sys.dont_write_bytecode = True
+    cwd = os.getcwd()
+    os.chdir(REF)
+    sys.path.insert(0, REF)
+    for m in [m for m in sys.modules if m.startswith("src")]:
+        del sys.modules[m]
+    old = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        runpy.run_path(os.path.join(REF, "src", "Planner", script), run_name="__main__")
+    finally:
+        sys.stdout = old
+        os.chdir(cwd)
+        sys.path.remove(REF)
+    return log, count[0]
+
+
+def make_sweep_fixtures():
+    """The reference's sequential-QP loops end to end: SE3Planner.py's backward sweeps and
+    CollocationBasedPlanner2D.py's SQP iterations, each QP built by the script from the answers to the previous ones.
+    Stored: a sample of the QPs (grouped by shape) with their certified optima."""
+    for script, name, every in [("SE3Planner.py", "se3", 8), ("CollocationBasedPlanner2D.py", "collocation2d", 1)]:
+        import time
+        t0 = time.time()
+        log, total = run_sweep(script, every)
+        groups = {}
+        for e in log:
+            P, q, G, h, A, b = e["args"]
+            key = (q.size, 0 if G is None else G.shape[0], 0 if A is None else A.shape[0])
+            groups.setdefault(key, []).append(e)
+        out = dict(source=np.array(f"src/Planner/{script} run to completion with solvers.qp answered by oracle.qp_oracle.solve_qp; "
+                                   f"every {every}th of {total} calls"), total_calls=total, n_groups=len(groups))
+        for gi, ((n, m, pe), es) in enumerate(sorted(groups.items())):
+            out[f"g{gi}_call"] = np.array([e["call"] for e in es])
+            out[f"g{gi}_P"] = np.stack([e["args"][0] for e in es])
+            out[f"g{gi}_q"] = np.stack([e["args"][1].reshape(-1) for e in es])
+            out[f"g{gi}_G"] = np.stack([e["args"][2] for e in es]) if m else np.zeros((len(es), 0, n))
+            out[f"g{gi}_h"] = np.stack([e["args"][3].reshape(-1) for e in es]) if m else np.zeros((len(es), 0))
+            out[f"g{gi}_A"] = np.stack([e["args"][4] for e in es]) if pe else np.zeros((len(es), 0, n))
+            out[f"g{gi}_b"] = np.stack([e["args"][5].reshape(-1) for e in es]) if pe else np.zeros((len(es), 0))
+            out[f"g{gi}_x"] = np.stack([e["x"] for e in es])
+            out[f"g{gi}_obj"] = np.array([e["obj"] for e in es])
+            out[f"g{gi}_kkt"] = np.array([e["kkt"] for e in es])
+            out[f"g{gi}_optimal"] = np.array([e["status"] == "optimal" for e in es])
+            print(f"sweep_{name}: group {gi} n={n} m={m} p={pe}: {len(es)} QPs, optimal {int(out[f'g{gi}_optimal'].sum())}, "
+                  f"max kkt {out[f'g{gi}_kkt'].max():.2e}")
+        np.savez_compressed(os.path.join(HERE, f"sweep_{name}.npz"), **out)
+        print(f"sweep_{name}: {total} solvers.qp calls, {len(log)} stored, {time.time() - t0:.0f} s")
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["ref", "mpc"]
     if "ref" in which:
         make_reference_fixtures()
     if "mpc" in which:
         make_mpc_fixtures()
+    if "sweep" in which:
+        make_sweep_fixtures()

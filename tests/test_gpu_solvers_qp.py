@@ -98,3 +98,28 @@ def test_batched_dense_and_cost_builder():
     for i in range(B):
         s = solve_qp(Q[i].cpu().numpy(), f[i, :, 0].cpu().numpy(), G[i], h[i])
         assert np.abs(X[i] - s["x"]).max() <= 1e-6 * max(np.abs(s["x"]).max(), 1e-300)
+
+
+@pytest.mark.parametrize("name", ["se3", "collocation2d"])
+def test_reference_sequential_sweeps_replay(name, golden_dir):
+    """QPs the reference's sequential loops build from the answers to their previous QPs
+    (SE3Planner.py:103-223 backward sweeps, CollocationBasedPlanner2D.py:85-365 SQP iterations), captured by running
+    the scripts end to end (tests/golden/make_golden.py sweep) -- solved here as batches through the C-ABI."""
+    import torch
+    from mpc_amd import solvers
+    g = np.load(os.path.join(golden_dir, f"sweep_{name}.npz"))
+    checked = 0
+    for gi in range(int(g["n_groups"])):
+        P, q, G, h, A, b = (g[f"g{gi}_{k}"] for k in "PqGhAb")
+        r = solvers.qp_batch(P, q, G if G.shape[1] else None, h if G.shape[1] else None,
+                             A if A.shape[1] else None, b if A.shape[1] else None)
+        x = r["x"].cpu().numpy(); obj = r["obj"].cpu().numpy(); st = r["status"].cpu().numpy()
+        for i in np.nonzero(g[f"g{gi}_optimal"])[0]:
+            xo, oo = g[f"g{gi}_x"][i], g[f"g{gi}_obj"][i]
+            if not np.isfinite(xo).all() or np.abs(xo).max() > 1e8:
+                continue            # the script's own iteration has blown up by then (SURVEY.md appendix, SE3Planner.py:114)
+            assert st[i] == 0, (gi, i)
+            assert np.abs(x[i] - xo).max() <= 1e-6 * max(1.0, np.abs(xo).max()), (gi, i)
+            assert abs(obj[i] - oo) <= 1e-8 * max(1.0, abs(oo)), (gi, i)
+            checked += 1
+    assert checked >= 8

@@ -166,3 +166,24 @@ def test_c_ipm_baseline_matches_golden(golden_dir):
     d = np.load(os.path.join(golden_dir, "ref_launch3d.npz"))
     x, z, st, _ = cb.solve_dense(d["P"], d["q"], d["G"], d["h"], abstol=1e-12, reltol=1e-12, feastol=1e-11)
     assert st == 0 and abs(0.5 * x @ d["P"] @ x + d["q"] @ x - float(d["objective"])) <= 1e-7 * abs(float(d["objective"]))
+
+
+def test_sweep_fixtures_are_certified_and_reproducible():
+    """tests/golden/sweep_*.npz: QPs from the reference's sequential loops run end to end.  Every stored optimum
+    carries a KKT certificate; re-solving a few reproduces it (the oracle is deterministic)."""
+    import os
+    import numpy as np
+    from oracle.qp_oracle import solve_qp, kkt_certificate
+    gd = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    for name, picks in (("se3", (0, 5)), ("collocation2d", (3,))):
+        g = np.load(os.path.join(gd, f"sweep_{name}.npz"))
+        assert int(g["total_calls"]) >= 10
+        for gi in range(int(g["n_groups"])):
+            ok = g[f"g{gi}_optimal"]
+            assert (g[f"g{gi}_kkt"][ok] <= 1e-9).all()
+        P, q, G, h, A, b = (g[f"g0_{k}"] for k in "PqGhAb")
+        for i in picks:
+            s = solve_qp(P[i], q[i], G[i] if G.shape[1] else None, h[i] if G.shape[1] else None,
+                         A[i] if A.shape[1] else None, b[i] if A.shape[1] else None)
+            xo = g["g0_x"][i]
+            assert np.abs(s["x"] - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
