@@ -77,11 +77,23 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        # one rank per GPU over RCCL; MPC_BENCH_BACKEND=gloo with several ranks on ONE device is only a rehearsal of
+        # this code path on a single-GPU box
+        backend = os.environ.get("MPC_BENCH_BACKEND", "nccl")
+        local = local % max(1, torch.cuda.device_count())
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+    verbose = bool(os.environ.get("MPC_BENCH_VERBOSE"))
+
+    def note(msg):
+        if verbose:
+            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
 
     from mpc_amd.configs import make_config
     from mpc_amd.planner import Planner
@@ -100,7 +112,17 @@ def main():
     opts = {}
     if args.max_iter is not None:
         opts["max_iter"] = args.max_iter
-    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    # collectives run on device tensors over RCCL; a rehearsal backend (gloo) gets host tensors
+    cdev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
+    flag = torch.zeros(1, dtype=torch.int32, device=cdev)
+    bar = torch.zeros(1, dtype=torch.int32, device=cdev)
+
+    def barrier():
+        # RCCL: the library's barrier; rehearsal backends: an all-reduce, which synchronises the ranks just the same
+        if dist.get_backend() == "nccl":
+            dist.barrier()
+        else:
+            dist.all_reduce(bar)
 
     def step():
         U = pl.solve(x0, **opts)
@@ -109,23 +131,26 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         return U
 
+    note("setup done")
     for _ in range(args.warmup):
         U = step()
+    note("warmup done")
     if dist is not None:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         U = step()
     if dist is not None:
-        dist.barrier()
+        barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 
+    note("timed region done")
     info = pl.info
     n_solved = int((info.status == 0).sum().item())
     iters_mean = float(info.iters.float().mean().item())
@@ -148,8 +173,9 @@ def main():
     both_ms = timed(lambda: pl.solve(x0, **opts), reps)
     polish_ms = max(both_ms - admm_ms, 0.0)
 
+    note("per-kernel timing done")
     allgather_ms = None
-    if dist is not None:
+    if dist is not None and cdev == dev:
         gathered = torch.empty((world,) + tuple(U.shape), dtype=U.dtype, device=dev)
         allgather_ms = timed(lambda: dist.all_gather_into_tensor(gathered, U), 5)
 
@@ -200,7 +226,7 @@ def main():
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()
+        barrier()
         dist.destroy_process_group()
 
 
