@@ -124,16 +124,32 @@ def main():
         else:
             dist.all_reduce(bar)
 
+    flags = [flag, flag.clone()]
+    pending = [None]
+    nstep = [0]
+
     def step():
+        # the all-reduce of the all-solved flag of step i is in flight while step i+1 computes (two flag buffers);
+        # the timed region ends with drain() + barrier, so every collective is inside it
         U = pl.solve(x0, **opts)
         if dist is not None:
-            flag.copy_((pl.info.status == 0).all().to(torch.int32).reshape(1))
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            f = flags[nstep[0] & 1]
+            nstep[0] += 1
+            f.copy_((pl.info.status == 0).all().to(torch.int32).reshape(1), non_blocking=True)
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = dist.all_reduce(f, op=dist.ReduceOp.MIN, async_op=True)
         return U
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     note("setup done")
     for _ in range(args.warmup):
         U = step()
+    drain()
     note("warmup done")
     if dist is not None:
         barrier()
@@ -141,6 +157,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         U = step()
+    drain()
     if dist is not None:
         barrier()
     torch.cuda.synchronize(dev)
