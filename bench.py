@@ -31,7 +31,7 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0
-ADMM_TRAFFIC_BYTES_65536 = (2 * 48193.74 + 212947.86) * 1024.0   # profiles/r01_v4_pmc.csv
+ADMM_TRAFFIC_BYTES_65536 = (2 * 49314.40 + 213303.90) * 1024.0   # profiles/r01_v5_pmc.csv
 
 
 def cpu_baseline(prob, seconds=15.0):
@@ -231,7 +231,7 @@ def main():
                          # FETCH_SIZE and WRITE_SIZE in separate runs; FETCH doubled as the gfx950 guide prescribes),
                          # measured at 65,536 instances and scaled with the batch; not re-measured by this script
                          "traffic": ADMM_TRAFFIC_BYTES_65536 * B / 65536.0,
-                         "traffic_source": "profiles/r01_v4_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of admm_shared_box_kernel)",
+                         "traffic_source": "profiles/r01_v5_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of admm_shared_box_kernel)",
                          "algorithmic_bytes": B * (8 * prob["nx"] + 3 * 8 * 16 * ((n + 15) // 16)),
                          "flops_per_launch": admm_flops, "launch_ms": admm_ms},
         }
