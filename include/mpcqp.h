@@ -169,6 +169,15 @@ int  mpcqp_solve_dense_strided(int device_id, int batch, int n, int m, int p, co
                                const double* b, long sb, double* x, double* z, double* y, double* obj, int* status,
                                int* iters, double* workspace, int* int_workspace, void* stream);
 
+/* the shared case split like factor / solve: set-up once per model (scaling, proximal Hessian, its inverse, scaled rows --
+ * into the workspace of QP 0), then any number of solves with new (q, h, b) on the SAME workspace
+ * (batch * mpcqp_dense_workspace doubles; the batch of the solves may not exceed what the workspace was sized for) */
+int  mpcqp_dense_shared_setup(int device_id, int n, int m, int p, const double* P, const double* G, const double* A,
+                              double* workspace, int* int_workspace, void* stream);
+int  mpcqp_dense_shared_solve(int device_id, int batch, int n, int m, int p, const double* q, const double* h,
+                              const double* b, double* x, double* z, double* y, double* obj, int* status, int* iters,
+                              double* workspace, int* int_workspace, void* stream);
+
 /* -- scenario model for the closed-loop LTV configuration (BASELINE.json configs[3]; the reference has no counterpart:
  * its scripts keep the model code inline, e.g. CollocationBasedPlanner2D.py:88-347) --------------------------------
  * Kinematic bicycle, state (x, y, psi, v), input (a, delta), explicit Euler.  For every rollout: nominal trajectory

@@ -57,6 +57,8 @@ SYMBOLS = [
     ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),
     ("mpcqp_ltv_bicycle", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 13),
     ("mpcqp_solve_dense_strided", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_long] * 6 + [C.c_void_p] * 8 + [C.c_void_p]),
+    ("mpcqp_dense_shared_setup", C.c_int, [C.c_int] * 4 + [C.c_void_p] * 6),
+    ("mpcqp_dense_shared_solve", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 12),
     ("mpcqp_solve_dense", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 14 + [C.c_void_p]),
 ]
 

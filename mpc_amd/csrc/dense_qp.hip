@@ -29,6 +29,8 @@ struct DenseParams {
     double* ws; long ws_stride;                // doubles per QP
     int* iws; long iws_stride;
     int n, m, p, B, max_steps, prox_iters, refine;
+    int phase;      // 0: everything per QP; 1: shared set-up only (one Hessian / constraint matrix for the batch,
+                    //    grid of 1, into the workspace of QP 0); 2: per-QP solve on that shared set-up
     double sigma_rel;
 };
 
@@ -231,7 +233,27 @@ __global__ __launch_bounds__(256) void dense_qp_kernel(DenseParams p) {
         for (auto v : vs) { *v = c; c += V; }
         w.act = p.iws + (size_t)qi * p.iws_stride;
     }
-
+    // shared set-up (phase 2): scaling, scaled Hessian and rows, inverse of Ps + sigma I live in the workspace of QP 0;
+    // this QP keeps its own vectors, Y, L and active list
+    double* sh_d = nullptr; double* sh_rn = nullptr; double* sh_t2 = nullptr;
+    {
+        double* c0 = p.ws;
+        const int V = max(max(n, mc), 1);
+        double* Ps0 = c0; double* Hi0 = Ps0 + (size_t)n * n; double* Cs0 = Hi0 + (size_t)3 * n * n;
+        double* v0 = Cs0 + (size_t)mc * n + (size_t)2 * K * n;
+        sh_d = v0; sh_rn = v0 + (size_t)3 * V;
+        sh_t2 = Hi0 + (size_t)n * n;        // the W block of QP 0: free once the inverse exists, never written in phase 2
+        if (p.phase == 2) { w.Ps = Ps0; w.Hi = Hi0; w.Cs = Cs0; }
+    }
+    int status = 0;     // 0 optimal, 1 unknown (step cap), 2 infeasible, 3 numerical
+    double sigma = 0.0;
+    if (p.phase == 2) {
+        for (int j = tid; j < n; j += 256) { w.d[j] = sh_d[j]; w.qs[j] = q[j] * sh_d[j]; w.xk[j] = 0.0; }
+        for (int r = tid; r < mc; r += 256) { w.rn[r] = sh_rn[r]; w.cs[r] = (r < pe ? b[r] : h[r - pe]) / sh_rn[r]; }
+        sigma = sh_t2[0];
+        status = (int)sh_t2[1];
+        __syncthreads();
+    } else {
     // ---- scaling -------------------------------------------------------------------------------------
     for (int j = tid; j < n; j += 256) {
         const double dg = P[(size_t)j * n + j];
@@ -269,12 +291,17 @@ __global__ __launch_bounds__(256) void dense_qp_kernel(DenseParams p) {
         w.Cs[idx] = src[j] * w.d[j] / w.rn[r];
     }
     for (int r = tid; r < mc; r += 256) w.cs[r] = (r < pe ? b[r] : h[r - pe]) / w.rn[r];
-    const double sigma = p.sigma_rel * fmax(dmax, 1e-300);
+    sigma = p.sigma_rel * fmax(dmax, 1e-300);
     for (int idx = tid; idx < n * n; idx += 256) w.W[idx] = w.Ps[idx] + ((idx / n == idx % n) ? sigma : 0.0);
     __syncthreads();
-    int status = 0;     // 0 optimal, 1 unknown (step cap), 2 infeasible, 3 numerical
     if (wg_chol(w.W, n, n, &sflag) >= 0) status = 3;     // P is not positive semidefinite
     if (status == 0) wg_inverse_from_chol(w.W, w.T, w.Hi, n);
+    if (p.phase == 1) {     // leave sigma and the status for the per-QP launch
+        __syncthreads();
+        if (tid == 0) { w.W[0] = sigma; w.W[1] = (double)status; }
+        return;
+    }
+    }
 
     // ---- proximal outer loop ---------------------------------------------------------------------------
     int k = 0, steps = 0, outer = 0;
@@ -511,6 +538,49 @@ int mpcqp_solve_dense_strided(int device_id, int batch, int n, int m, int p, con
     d.iws = int_workspace; d.iws_stride = ic;
     d.n = n; d.m = m; d.p = p; d.B = batch;
     d.max_steps = 20 * (n + m + p) + 100; d.prox_iters = 30; d.refine = 2; d.sigma_rel = 1e-6;
+    // one Hessian and one set of rows for the whole batch: scale and factor them ONCE (a grid of one workgroup into the
+    // workspace of QP 0), then every QP solves on that shared set-up with its own q, h, b
+    const bool shared = batch > 1 && sP == 0 && (m == 0 || sG == 0) && (p == 0 || sA == 0);
+    if (shared) {
+        d.phase = 1;
+        hipLaunchKernelGGL(dense_qp_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), d);
+        if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+        d.phase = 2;
+    } else d.phase = 0;
+    hipLaunchKernelGGL(dense_qp_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d);
+    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+int mpcqp_dense_shared_setup(int device_id, int n, int m, int p, const double* P, const double* G, const double* A,
+                             double* workspace, int* int_workspace, void* stream) {
+    if (n < 1 || m < 0 || p < 0 || !P || !workspace || !int_workspace || (m > 0 && !G) || (p > 0 && !A)) return MPCQP_EINVAL;
+    if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
+    DenseParams d{};
+    d.P = P; d.q = workspace; d.G = m ? G : nullptr; d.h = m ? workspace : nullptr; d.A = p ? A : nullptr; d.b = p ? workspace : nullptr;
+    long ic = 0;
+    d.ws = workspace; d.ws_stride = mpcqp_dense_workspace(n, m, p, &ic);
+    d.iws = int_workspace; d.iws_stride = ic;
+    d.n = n; d.m = m; d.p = p; d.B = 1;
+    d.max_steps = 0; d.prox_iters = 0; d.refine = 0; d.sigma_rel = 1e-6; d.phase = 1;
+    hipLaunchKernelGGL(dense_qp_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), d);
+    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+int mpcqp_dense_shared_solve(int device_id, int batch, int n, int m, int p, const double* q, const double* h, const double* b,
+                             double* x, double* z, double* y, double* obj, int* status, int* iters,
+                             double* workspace, int* int_workspace, void* stream) {
+    if (batch < 1 || n < 1 || m < 0 || p < 0 || !q || !x || !workspace || !int_workspace || (m > 0 && !h) || (p > 0 && !b))
+        return MPCQP_EINVAL;
+    if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
+    DenseParams d{};
+    d.P = nullptr; d.q = q; d.G = nullptr; d.h = m ? h : nullptr; d.A = nullptr; d.b = p ? b : nullptr;
+    d.sq = n; d.sh = m; d.sb = p;
+    d.x = x; d.z = z; d.y = y; d.obj = obj; d.status = status; d.iters = iters;
+    long ic = 0;
+    d.ws = workspace; d.ws_stride = mpcqp_dense_workspace(n, m, p, &ic);
+    d.iws = int_workspace; d.iws_stride = ic;
+    d.n = n; d.m = m; d.p = p; d.B = batch;
+    d.max_steps = 20 * (n + m + p) + 100; d.prox_iters = 30; d.refine = 2; d.sigma_rel = 1e-6; d.phase = 2;
     hipLaunchKernelGGL(dense_qp_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d);
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
 }

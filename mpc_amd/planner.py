@@ -280,19 +280,38 @@ class Planner:
                     H=self.get("H"), F=self.get("F"), f0=self.get("f0"))
 
     def _solve_general(self, x0, want_multipliers):
-        from . import solvers
         gen = self._gen
-        q = torch.addmm(gen["f0"].unsqueeze(0), x0, gen["F"].t())          # q = F x0 + f0
-        h = gen["h0"].unsqueeze(0) - x0 @ gen["E"].t()                     # h = h0 - E x0
-        r = solvers.qp_batch(gen["H"], q, gen["G"], h, device=self.device)
-        B = x0.shape[0]
-        st = r["status"]
+        dev = self.device
+        lib = self._lib
+        B, n, m = x0.shape[0], self.n, gen["G"].shape[0]
+        q = torch.addmm(gen["f0"].unsqueeze(0), x0, gen["F"].t()).contiguous()        # q = F x0 + f0
+        h = (gen["h0"].unsqueeze(0) - x0 @ gen["E"].t()).contiguous()                 # h = h0 - E x0
+        ni = C.c_long(0)
+        nd = lib.mpcqp_dense_workspace(n, m, 0, C.byref(ni))
+        if gen.get("ws") is None or gen["ws_batch"] < B:        # shared set-up: once per model (and per larger batch)
+            gen["ws"] = torch.empty(B * nd, dtype=torch.float64, device=dev)
+            gen["iws"] = torch.empty(B * ni.value, dtype=torch.int32, device=dev)
+            gen["ws_batch"] = B
+            rc = lib.mpcqp_dense_shared_setup(dev.index or 0, n, m, 0, _ptr(gen["H"]), _ptr(gen["G"]), C.c_void_p(0),
+                                              _ptr(gen["ws"]), _ptr(gen["iws"]), self._stream())
+            if rc != _lib.OK:
+                raise RuntimeError(f"mpcqp_dense_shared_setup failed with code {rc}")
+        x = torch.empty((B, n), dtype=torch.float64, device=dev)
+        z = torch.zeros((B, max(m, 1)), dtype=torch.float64, device=dev)
+        obj = torch.empty(B, dtype=torch.float64, device=dev)
+        st = torch.empty(B, dtype=torch.int32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        rc = lib.mpcqp_dense_shared_solve(dev.index or 0, B, n, m, 0, _ptr(q), _ptr(h), C.c_void_p(0), _ptr(x), _ptr(z),
+                                          C.c_void_p(0), _ptr(obj), _ptr(st), _ptr(iters), _ptr(gen["ws"]), _ptr(gen["iws"]),
+                                          self._stream())
+        if rc != _lib.OK:
+            raise RuntimeError(f"mpcqp_dense_shared_solve failed with code {rc}")
         # dense status 0 optimal | 1 step cap | 2 infeasible | 3 numerical  ->  MPCQP_SOLVED | MPCQP_MAX_ITER | 3 | 4
         status = torch.where(st == 0, torch.zeros_like(st), st + 1)
-        self.info = SimpleNamespace(iters=torch.zeros(B, dtype=torch.int32, device=self.device), status=status,
-                                    obj=r["obj"], prim_res=None, dual_res=None,
-                                    polish_steps=r["iters"] % 1000, lam=r["z"] if want_multipliers else None)
-        return r["x"].reshape(B, self.N, self.nu)
+        self.info = SimpleNamespace(iters=torch.zeros(B, dtype=torch.int32, device=dev), status=status,
+                                    obj=obj, prim_res=None, dual_res=None,
+                                    polish_steps=iters % 1000, lam=z[:, :m] if want_multipliers else None)
+        return x.reshape(B, self.N, self.nu)
 
     def solve(self, x0, warm_start=None, want_multipliers=False, **opts):
         """x0 (B,nx) -> U (B,N,nu) on the device; per-instance diagnostics in ``self.info``
