@@ -262,3 +262,31 @@ def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch):
     assert bool(((pl.info.obj - obj).abs() <= 1e-8 * obj.abs().clamp_min(1e-9)).all())
     # the bounds do bind: on average more than once per instance for the quadrotors, now and then for the cart-poles
     assert int((~free).sum()) > (batch if cfg == 3 else 0)
+
+
+@pytest.mark.parametrize("nx,nu,N", [(3, 1, 25), (5, 3, 11), (33, 2, 12), (2, 1, 128)])
+def test_odd_shapes_match_oracle(nx, nu, N):
+    """Shapes off the beaten path of the polish fast path: odd n (no 16-byte row pairs), n not a multiple of 16,
+    nx + 1 > 32 (the fast path hands over to the wave-per-instance kernel), n = 128 (largest ADMM tile count)."""
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_box_qp
+    rng = np.random.default_rng(nx * 100 + N)
+    A = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    B = rng.standard_normal((nx, nu)) / np.sqrt(nx)
+    Q = np.eye(nx); R = 0.05 * np.eye(nu)
+    batch = 70
+    x0 = rng.uniform(-2, 2, (batch, nx))
+    umin, umax = -0.3 * np.ones(nu), 0.4 * np.ones(nu)
+    pl = Planner(nx, nu, N).set_model(A, B).set_cost(Q, R, 2 * Q).set_constraints(umin, umax)
+    U = pl.solve(x0).cpu().numpy().reshape(batch, -1)
+    assert (pl.info.status.cpu().numpy() == 0).all()
+    obj = pl.info.obj.cpu().numpy()
+    H, F, f0 = mo.condense(dict(N=N, nx=nx, nu=nu, A=A, B=B, Q=Q, R=R, P=2 * Q))
+    nact = 0
+    for i in range(0, batch, 7):
+        s = solve_box_qp(H, F @ x0[i] + f0, np.tile(umin, N), np.tile(umax, N))
+        assert np.abs(U[i] - s["x"]).max() <= PRIMAL_RTOL * max(1.0, np.abs(s["x"]).max()), i
+        assert abs(obj[i] - s["primal objective"]) <= OBJ_RTOL * max(abs(s["primal objective"]), 1e-12), i
+        nact += int(((np.abs(s["x"] - np.tile(umin, N)) < 1e-9) | (np.abs(s["x"] - np.tile(umax, N)) < 1e-9)).sum())
+    assert nact > 0
