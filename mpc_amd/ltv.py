@@ -58,6 +58,8 @@ class ClosedLoopLTV:
         self.plan = None            # (B, N, nu) current input plan
         self.last = None            # tensors of the last QP, kept for inspection
         self._dx0 = None
+        self._buf = None            # persistent linearisation buffers (bicycle kernel)
+        self._registered = False
 
     def nominal(self, x, plan):
         xs = [x]
@@ -74,10 +76,14 @@ class ClosedLoopLTV:
             from . import _lib
             lib = _lib.load()
             f64 = dict(dtype=torch.float64, device=self.device)
-            out = dict(xbar=torch.empty((Bn, N + 1, nx), **f64), A=torch.empty((Bn, N, nx, nx), **f64),
-                       B=torch.empty((Bn, N, nx, nu), **f64), xr=torch.empty((Bn, N, nx), **f64),
-                       ur=torch.empty((Bn, N, nu), **f64), lb=torch.empty((Bn, N, nu), **f64),
-                       ub=torch.empty((Bn, N, nu), **f64))
+            if self._buf is None or self._buf["A"].shape[0] != Bn:
+                # persistent buffers: the handle remembers their addresses, so later steps only re-run the kernels
+                self._buf = dict(xbar=torch.empty((Bn, N + 1, nx), **f64), A=torch.empty((Bn, N, nx, nx), **f64),
+                                 B=torch.empty((Bn, N, nx, nu), **f64), xr=torch.empty((Bn, N, nx), **f64),
+                                 ur=torch.empty((Bn, N, nu), **f64), lb=torch.empty((Bn, N, nu), **f64),
+                                 ub=torch.empty((Bn, N, nu), **f64))
+                self._registered = False
+            out = self._buf
             p = lambda t: C.c_void_p(t.data_ptr())
             rc = lib.mpcqp_ltv_bicycle(self.device.index or 0, Bn, N, self.model.dt, self.model.L, p(x.contiguous()),
                                        p(ubar), p(x_ref.contiguous()), p(self.u_min), p(self.u_max), p(out["xbar"]),
@@ -100,9 +106,13 @@ class ClosedLoopLTV:
         ubar = self.plan
         lin = self.linearize(x, ubar, x_ref)
         pl = self.pl
-        pl.set_model(lin["A"], lin["B"])
-        pl.set_cost(self.Q, self.R, self.P, x_ref=lin["xr"], u_ref=lin["ur"])
-        pl.set_constraints(lin["lb"], lin["ub"])
+        if lin is self._buf and self._registered:
+            pl.refresh()        # same buffers, new contents: assemble + factor again, no pointer traffic
+        else:
+            pl.set_model(lin["A"], lin["B"])
+            pl.set_cost(self.Q, self.R, self.P, x_ref=lin["xr"], u_ref=lin["ur"])
+            pl.set_constraints(lin["lb"], lin["ub"])
+            self._registered = lin is self._buf
         if self._dx0 is None or self._dx0.shape[0] != Bn:
             self._dx0 = torch.zeros((Bn, self.model.nx), dtype=torch.float64, device=self.device)
         dU = pl.solve(self._dx0, warm_start=(warm and not first), **opts)

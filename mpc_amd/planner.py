@@ -231,6 +231,12 @@ class Planner:
         self._dirty = True
         return self
 
+    def refresh(self):
+        """The registered model / cost / constraint buffers have new CONTENTS (same addresses): re-run assemble and
+        factor before the next solve."""
+        self._dirty = True
+        return self
+
     # ---- kernels -----------------------------------------------------------------------
     def setup(self, rho=None, keep_state=False):
         """assemble (rollout, H, F, f0) + factor; called lazily by solve().  With ``self.no_sync`` (closed loops)
