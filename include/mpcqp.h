@@ -178,6 +178,20 @@ int  mpcqp_dense_shared_solve(int device_id, int batch, int n, int m, int p, con
                               const double* b, double* x, double* z, double* y, double* obj, int* status, int* iters,
                               double* workspace, int* int_workspace, void* stream);
 
+/* the same shared case when MANY rows meet few active ones (state / polytopic rows over a long horizon: BASELINE.json
+ * configs[4], 13,200 rows x 600 variables; rows as in LaunchPlannerQPFormulation.py:109-114, Launch3DPlanner.py:134-142):
+ * the set-up additionally forms CH = Cs Hi (m x n) and the dual Hessian Cs Hi Cs' (m x m), and each solve keeps the row
+ * residuals up to date through rows of that matrix instead of re-evaluating G x.  Needs P positive definite (the
+ * condensed MPC Hessian is: Rbar > 0) and inequality rows only; at most 96 rows may be active at once (status 3
+ * beyond).  Same outputs and status codes as mpcqp_solve_dense; iters = active-set steps.
+ * shared_ws: mpcqp_rows_workspace(n, m, &per) doubles, written by the set-up, read-only afterwards;
+ * int_ws: n ints (set-up only); instance_ws: batch * per doubles. */
+long mpcqp_rows_workspace(int n, int m, long* per_instance);
+int  mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double* G, double* shared_ws, int* int_ws,
+                      void* stream);
+int  mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, const double* h, double* x, double* z,
+                      double* obj, int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream);
+
 /* -- scenario model for the closed-loop LTV configuration (BASELINE.json configs[3]; the reference has no counterpart:
  * its scripts keep the model code inline, e.g. CollocationBasedPlanner2D.py:88-347) --------------------------------
  * Kinematic bicycle, state (x, y, psi, v), input (a, delta), explicit Euler.  For every rollout: nominal trajectory

@@ -513,6 +513,25 @@ __global__ __launch_bounds__(256) void dense_qp_kernel(DenseParams p) {
 
 }  // namespace
 
+static int shared_setup(int n, int m, int p, const double* P, const double* G, const double* A, double* workspace,
+                        int* int_workspace, double sigma_rel, hipStream_t stream) {
+    DenseParams d{};
+    d.P = P; d.q = workspace; d.G = m ? G : nullptr; d.h = m ? workspace : nullptr; d.A = p ? A : nullptr; d.b = p ? workspace : nullptr;
+    long ic = 0;
+    d.ws = workspace; d.ws_stride = mpcqp_dense_workspace(n, m, p, &ic);
+    d.iws = int_workspace; d.iws_stride = ic;
+    d.n = n; d.m = m; d.p = p; d.B = 1;
+    d.max_steps = 0; d.prox_iters = 0; d.refine = 0; d.sigma_rel = sigma_rel; d.phase = 1;
+    hipLaunchKernelGGL(dense_qp_kernel, dim3(1), dim3(256), 0, stream, d);
+    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+// rows_qp.hip: the same shared set-up without the proximal term (P positive definite), inequality rows only
+int dense_shared_setup_sigma(int n, int m, const double* P, const double* G, double* workspace, int* int_workspace,
+                             double sigma_rel, hipStream_t stream) {
+    return shared_setup(n, m, 0, P, G, nullptr, workspace, int_workspace, sigma_rel, stream);
+}
+
 extern "C" {
 
 long mpcqp_dense_workspace(int n, int m, int p, long* int_count) {
@@ -555,15 +574,7 @@ int mpcqp_dense_shared_setup(int device_id, int n, int m, int p, const double* P
                              double* workspace, int* int_workspace, void* stream) {
     if (n < 1 || m < 0 || p < 0 || !P || !workspace || !int_workspace || (m > 0 && !G) || (p > 0 && !A)) return MPCQP_EINVAL;
     if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
-    DenseParams d{};
-    d.P = P; d.q = workspace; d.G = m ? G : nullptr; d.h = m ? workspace : nullptr; d.A = p ? A : nullptr; d.b = p ? workspace : nullptr;
-    long ic = 0;
-    d.ws = workspace; d.ws_stride = mpcqp_dense_workspace(n, m, p, &ic);
-    d.iws = int_workspace; d.iws_stride = ic;
-    d.n = n; d.m = m; d.p = p; d.B = 1;
-    d.max_steps = 0; d.prox_iters = 0; d.refine = 0; d.sigma_rel = 1e-6; d.phase = 1;
-    hipLaunchKernelGGL(dense_qp_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), d);
-    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+    return shared_setup(n, m, p, P, G, A, workspace, int_workspace, 1e-6, static_cast<hipStream_t>(stream));
 }
 
 int mpcqp_dense_shared_solve(int device_id, int batch, int n, int m, int p, const double* q, const double* h, const double* b,

@@ -1,0 +1,524 @@
+// Shared-matrix QPs with many inequality rows, solved in CONSTRAINT space.
+//
+//     min 1/2 x'Px + q_b'x   s.t.  G x <= h_b        b = 0 .. batch-1,  one (P, G) for the batch, P positive definite
+//
+// This is the condensed MPC problem with state-box / polytopic rows (reference: rows of the
+// prediction matrix stacked under the input box, LaunchPlannerQPFormulation.py:109-114, Launch3DPlanner.py:134-142,
+// handed to cvxopt.solvers.qp at LaunchPlannerQPFormulation.py:173): n = N nu variables, m = 2 N (nu + nx + nc) rows
+// (13,200 x 600 for BASELINE.json config 5), a few of which bind.
+//
+// dense_qp.hip re-evaluates all m rows against x after every active-set change: m*n doubles per step per instance
+// (63 MB for config 5) -- that pass is ~all of its time.  Here the set-up forms, once per (P, G),
+//     CH   = Cs Hi          (m x n)    row r = the step direction of row r
+//     Gram = Cs Hi Cs'      (m x m)    the dual Hessian
+// (Cs = scaled rows, Hi = inverse scaled Hessian: both from the dense kernel's shared set-up) with an fp64 MFMA
+// GEMM, and each instance keeps its row residuals res = Cs x - cs up to date through Gram rows:
+//     x <- x - t Hi (n_p - N'r)      =>      res <- res - t (Gram[p,:] - sum_a r_a Gram[A_a,:])
+// i.e. (k+1) rows of m doubles instead of the m x n pass, and the Schur complement of the active rows is a gather
+// S = Gram[A, A].  The iteration itself is the same Goldfarb-Idnani dual active-set method as dense_qp.hip (same
+// pivoting rules, same thresholds), so both paths land on the same vertex; the tests compare them.
+//
+// Per solve: scale (q, h) -> GEMM xu = -Qs Hi -> GEMM res = Xu Cs' - cs -> one 512-thread workgroup per instance.
+#include "common.h"
+#include <algorithm>
+#include <cstdint>
+
+int dense_shared_setup_sigma(int n, int m, const double* P, const double* G, double* workspace, int* int_workspace,
+                             double sigma_rel, hipStream_t stream);
+
+namespace {
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- C (M x N) = alpha A (M x K) B' (B is N x K) + beta C : fp64 MFMA, 64 x 64 per workgroup, 32 x 32 per wave ----------
+struct GemmParams {
+    const double *A, *B;
+    double* C;
+    long lda, ldb, ldc;
+    int M, N, K, vec;
+    double alpha, beta;
+};
+
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams g) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.y * 64 + (wave >> 1) * 32, j0 = blockIdx.x * 64 + (wave & 1) * 32;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0, 0, 0, 0};
+    const double* ar[2]; const double* br[2];
+    bool av[2], bv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = i0 + 16 * t + col, j = j0 + 16 * t + col;
+        av[t] = i < g.M; bv[t] = j < g.N;
+        ar[t] = g.A + (size_t)min(i, g.M - 1) * g.lda;
+        br[t] = g.B + (size_t)min(j, g.N - 1) * g.ldb;
+    }
+    // each lane owns 4 consecutive k of every 16 (the k order inside a product is free as long as A and B agree)
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        double a[2][4], b[2][4];
+        const int kb = k0 + 4 * kq;
+        if (g.vec && k0 + 16 <= g.K) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double2 a0 = *reinterpret_cast<const double2*>(ar[t] + kb), a1 = *reinterpret_cast<const double2*>(ar[t] + kb + 2);
+                const double2 b0 = *reinterpret_cast<const double2*>(br[t] + kb), b1 = *reinterpret_cast<const double2*>(br[t] + kb + 2);
+                a[t][0] = a0.x; a[t][1] = a0.y; a[t][2] = a1.x; a[t][3] = a1.y;
+                b[t][0] = b0.x; b[t][1] = b0.y; b[t][2] = b1.x; b[t][3] = b1.y;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = kb + e;
+                    a[t][e] = k < g.K ? ar[t][k] : 0.0;
+                    b[t][e] = k < g.K ? br[t][k] : 0.0;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!av[t]) a[t][e] = 0.0;
+                if (!bv[t]) b[t][e] = 0.0;
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = mfma_f64(a[ti][e], b[tj][e], acc[ti][tj]);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int i = i0 + 16 * ti + kq + 4 * r4, j = j0 + 16 * tj + col;
+                if (i < g.M && j < g.N) {
+                    double* c = g.C + (size_t)i * g.ldc + j;
+                    double v = g.alpha * acc[ti][tj][r4];
+                    if (g.beta != 0.0) v += g.beta * *c;
+                    *c = v;
+                }
+            }
+}
+
+int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int M, int N, int K,
+                   double alpha, double beta, hipStream_t st) {
+    GemmParams g;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
+    g.vec = (lda % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0);
+    hipLaunchKernelGGL(gemm_nt_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
+    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+// ---- per-instance scaling of (q, h) ------------------------------------------------------------------------------------
+struct Layout {
+    // shared block: [dense set-up of "QP 0" | CH | Gram]
+    long nd0;
+    // per-instance block
+    long o_res, o_cs, o_qs, o_xu, o_x, o_t1, o_dv, stride;
+};
+
+Layout make_layout(int n, int m) {
+    Layout l;
+    l.nd0 = mpcqp_dense_workspace(n, m, 0, nullptr);
+    l.nd0 += l.nd0 & 1;
+    const long me = m + (m & 1), ne = n + (n & 1);
+    l.o_res = 0; l.o_cs = me; l.o_qs = 2 * me; l.o_xu = l.o_qs + ne; l.o_x = l.o_xu + ne; l.o_t1 = l.o_x + ne; l.o_dv = l.o_t1 + ne;
+    l.stride = l.o_dv + ne;
+    return l;
+}
+
+struct SharedPtrs { const double *Ps, *Hi, *W0, *Cs, *d, *rn; };
+
+__host__ __device__ inline SharedPtrs shared_ptrs(const double* ws0, int n, int m) {
+    // the layout of dense_qp.hip's workspace for one QP (p = 0)
+    SharedPtrs s;
+    const long V = n > m ? n : (m > 1 ? m : 1);
+    s.Ps = ws0; s.Hi = ws0 + (size_t)n * n; s.W0 = ws0 + (size_t)2 * n * n; s.Cs = ws0 + (size_t)4 * n * n;
+    const double* v0 = s.Cs + (size_t)m * n + (size_t)2 * n * n;
+    s.d = v0; s.rn = v0 + 3 * V;
+    return s;
+}
+
+struct PrepParams { const double *q, *h, *ws0; double* inst; Layout l; int n, m, B; };
+
+__global__ __launch_bounds__(256) void rows_prep_kernel(PrepParams p) {
+    const SharedPtrs s = shared_ptrs(p.ws0, p.n, p.m);
+    const long per = (long)p.n + p.m, total = per * p.B;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / per), e = (int)(i % per);
+        double* c = p.inst + (size_t)b * p.l.stride;
+        if (e < p.n) c[p.l.o_qs + e] = p.q[(size_t)b * p.n + e] * s.d[e];
+        else {
+            const int r = e - p.n;
+            const double v = p.h[(size_t)b * p.m + r] / s.rn[r];
+            c[p.l.o_cs + r] = v;
+            c[p.l.o_res + r] = v;        // the residual GEMM turns this into Cs xu - cs
+        }
+    }
+}
+
+// ---- the active-set iteration, one workgroup per instance ---------------------------------------------------------------
+constexpr int RT = 512;
+
+struct RowsParams {
+    const double *ws0, *CH, *Gram;
+    double* inst;
+    Layout l;
+    double *x, *z, *obj;
+    int *status, *iters;
+    int n, m, B, KL, max_steps, refine;
+};
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__device__ double blk_sum(double v, double* red) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < RT / 64; ++w) s += red[w];
+    return s;
+}
+
+// the largest v over candidates (idx >= 0), ties to the lowest index
+__device__ void blk_argmax(double v, int idx, double* red, int* redi, double& vout, int& iout) {
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const double ov = __shfl_xor(v, o); const int oi = __shfl_xor(idx, o);
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = v; redi[threadIdx.x >> 6] = idx; }
+    __syncthreads();
+    v = red[0]; idx = redi[0];
+    for (int w = 1; w < RT / 64; ++w) {
+        const double ov = red[w]; const int oi = redi[w];
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+    vout = v; iout = idx;
+}
+
+// wave 0, vector in LDS: v <- L^-1 v / v <- L^-T v for the k x k lower factor L (leading dimension ld)
+__device__ void w0_fwd(const double* L, int ld, int k, double* v, int lane) {
+    for (int c = 0; c < k; ++c) {
+        const double yc = v[c] / L[c * ld + c];
+        wave_sync();
+        if (lane == 0) v[c] = yc;
+        for (int i = c + 1 + lane; i < k; i += 64) v[i] -= L[i * ld + c] * yc;
+        wave_sync();
+    }
+}
+
+__device__ void w0_bwd(const double* L, int ld, int k, double* v, int lane) {
+    for (int c = k - 1; c >= 0; --c) {
+        const double yc = v[c] / L[c * ld + c];
+        wave_sync();
+        if (lane == 0) v[c] = yc;
+        for (int i = lane; i < c; i += 64) v[i] -= L[c * ld + i] * yc;
+        wave_sync();
+    }
+}
+
+// wave 0: remove member j of the active list
+__device__ void w0_remove(int* act, double* lam, int j, int k, int lane) {
+    for (int base = j; base < k - 1; base += 64) {
+        const int a = base + lane;
+        int na = 0; double nl = 0.0;
+        if (a < k - 1) { na = act[a + 1]; nl = lam[a + 1]; }
+        wave_sync();
+        if (a < k - 1) { act[a] = na; lam[a] = nl; }
+        wave_sync();
+    }
+}
+
+// L <- chol(Gram[act, act]); a member whose pivot falls below 1e-12 of its diagonal is dependent on the ones before
+// it and is removed.  Returns the (possibly reduced) k.
+__device__ int rows_rebuild(const double* Gram, int m, double* L, int KL, int* act, double* lam, int k, int* sflag) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (;;) {
+        __syncthreads();
+        for (int idx = tid; idx < k * k; idx += RT) {
+            const int a = idx / k, c = idx % k;
+            if (c <= a) L[a * KL + c] = Gram[(size_t)act[a] * m + act[c]];
+        }
+        __syncthreads();
+        if (wave == 0) {
+            int bad = -1;
+            for (int j = 0; j < k; ++j) {
+                const double dj = L[j * KL + j];
+                const double d0 = Gram[(size_t)act[j] * m + act[j]];
+                if (!(dj > 1e-12 * d0)) { bad = j; break; }
+                const double sj = sqrt(dj), inv = 1.0 / sj;
+                wave_sync();
+                if (lane == 0) L[j * KL + j] = sj;
+                for (int i = j + 1 + lane; i < k; i += 64) L[i * KL + j] *= inv;
+                wave_sync();
+                const int rem = k - j - 1;
+                for (int idx = lane; idx < rem * rem; idx += 64) {
+                    const int i = j + 1 + idx / rem, c = j + 1 + idx % rem;
+                    if (c <= i) L[i * KL + c] -= L[i * KL + j] * L[c * KL + j];
+                }
+                wave_sync();
+            }
+            if (lane == 0) *sflag = bad;
+        }
+        __syncthreads();
+        const int bad = *sflag;
+        if (bad < 0) return k;
+        if (wave == 0) w0_remove(act, lam, bad, k, lane);
+        --k;
+        if (k == 0) { __syncthreads(); return 0; }
+    }
+}
+
+__global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ double red[RT / 64];
+    __shared__ int redi[RT / 64];
+    __shared__ int sflag;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = p.n, m = p.m, KL = p.KL, qi = blockIdx.x;
+    double* L = reinterpret_cast<double*>(smem);        // KL x KL: lower Cholesky factor of S = Gram[act, act]
+    double* lv = L + (size_t)KL * KL;
+    double* rv = lv + KL;
+    double* lam = rv + KL;
+    double* dl = lam + KL;
+    int* act = reinterpret_cast<int*>(dl + KL);
+    const SharedPtrs s = shared_ptrs(p.ws0, n, m);
+    double* c = p.inst + (size_t)qi * p.l.stride;
+    double* res = c + p.l.o_res; const double* cs = c + p.l.o_cs; const double* qs = c + p.l.o_qs;
+    const double* xu = c + p.l.o_xu; double* x = c + p.l.o_x; double* t1 = c + p.l.o_t1; double* dv = c + p.l.o_dv;
+
+    int status = (int)s.W0[1];      // 0 optimal, 1 step cap, 2 infeasible, 3 numerical (P not positive definite, or more than KL rows bind)
+    int k = 0, steps = 0;
+
+    while (status == 0) {
+        // the most violated row that is not in the active set
+        double best = 0.0; int bi = -1;
+        for (int r = tid; r < m; r += RT) {
+            const double v = res[r];
+            if (v > 1e-12 * fmax(1.0, fabs(cs[r])) && (bi < 0 || v > best)) {
+                bool member = false;
+                for (int a = 0; a < k; ++a) member |= act[a] == r;
+                if (!member) { best = v; bi = r; }
+            }
+        }
+        double v0; int pp;
+        blk_argmax(best, bi, red, redi, v0, pp);
+        if (pp < 0) break;
+        const double* Grow = p.Gram + (size_t)pp * m;
+        const double nHn = Grow[pp];
+        double accl = 0.0;
+        bool added = false;
+        while (!added) {
+            if (++steps > p.max_steps) { status = 1; break; }
+            __syncthreads();
+            for (int a = tid; a < k; a += RT) lv[a] = Grow[act[a]];
+            __syncthreads();
+            if (wave == 0) {
+                w0_fwd(L, KL, k, lv, lane);
+                for (int a = lane; a < k; a += 64) rv[a] = lv[a];
+                wave_sync();
+                w0_bwd(L, KL, k, rv, lane);
+            }
+            __syncthreads();
+            // every wave evaluates the step lengths redundantly (k <= KL): identical arithmetic, uniform control flow
+            double part = 0.0;
+            for (int a = lane; a < k; a += 64) part += lv[a] * lv[a];
+            const double d2 = nHn - wave_sum(part);
+            const bool dep = !(d2 > 1e-13 * nHn);
+            const double t2 = dep ? 1e300 : v0 / d2;
+            double tr = 1e300; int jb = -1;
+            for (int a = lane; a < k; a += 64)
+                if (rv[a] > 0.0) {
+                    const double t = lam[a] / rv[a];
+                    if (t < tr) { tr = t; jb = a; }
+                }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) {
+                const double ot = __shfl_xor(tr, o); const int oj = __shfl_xor(jb, o);
+                if (oj >= 0 && (jb < 0 || ot < tr || (ot == tr && oj < jb))) { tr = ot; jb = oj; }
+            }
+            if (jb < 0 && dep) { status = 2; break; }           // no step possible: infeasible
+            const bool full = !dep && t2 <= tr;
+            const double t = full ? t2 : tr;
+            if (!dep)
+                for (int r0 = 0; r0 < m; r0 += 4 * RT) {
+                    double sv[4]; int r[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { r[e] = r0 + e * RT + tid; sv[e] = r[e] < m ? Grow[r[e]] : 0.0; }
+                    for (int a = 0; a < k; ++a) {
+                        const double cf = rv[a];
+                        const double* ga = p.Gram + (size_t)act[a] * m;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (r[e] < m) sv[e] -= cf * ga[r[e]];
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) if (r[e] < m) res[r[e]] -= t * sv[e];
+                }
+            __syncthreads();
+            if (wave == 0) {
+                for (int a = lane; a < k; a += 64) lam[a] -= t * rv[a];
+                wave_sync();
+            }
+            accl += t;
+            if (full) {
+                if (k >= KL) { status = 3; break; }
+                if (wave == 0) {
+                    for (int a = lane; a < k; a += 64) L[k * KL + a] = lv[a];
+                    if (lane == 0) { L[k * KL + k] = sqrt(d2); act[k] = pp; lam[k] = accl; }
+                }
+                ++k;
+                added = true;
+                __syncthreads();
+            } else {
+                if (!dep) v0 -= t * d2;
+                if (wave == 0) w0_remove(act, lam, jb, k, lane);
+                --k;
+                k = rows_rebuild(p.Gram, m, L, KL, act, lam, k, &sflag);
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- x = xu - CH[act,:]' lam, then refinement on the final active set with Ps / Cs themselves ----------------------
+    for (int j = tid; j < n; j += RT) {
+        double v = xu[j];
+        for (int a = 0; a < k; ++a) v -= lam[a] * p.CH[(size_t)act[a] * n + j];
+        x[j] = v;
+    }
+    __syncthreads();
+    if (status == 0)
+        for (int itr = 0; itr < p.refine; ++itr) {
+            for (int j = tid; j < n; j += RT) {             // g = Ps x + qs + N' lam   (Ps symmetric: column reads coalesce)
+                double v = qs[j];
+                for (int i = 0; i < n; ++i) v += s.Ps[(size_t)i * n + j] * x[i];
+                for (int a = 0; a < k; ++a) v += s.Cs[(size_t)act[a] * n + j] * lam[a];
+                t1[j] = v;
+            }
+            __syncthreads();
+            for (int j = tid; j < n; j += RT) {             // dv = Hi g
+                double v = 0.0;
+                for (int i = 0; i < n; ++i) v += s.Hi[(size_t)i * n + j] * t1[i];
+                dv[j] = v;
+            }
+            __syncthreads();
+            for (int a = wave; a < k; a += RT / 64) {       // N (x - dv) - cs on the active rows
+                const double* na = s.Cs + (size_t)act[a] * n;
+                double v = 0.0;
+                for (int j = lane; j < n; j += 64) v += na[j] * (x[j] - dv[j]);
+                v = wave_sum(v);
+                if (lane == 0) dl[a] = v - cs[act[a]];
+            }
+            __syncthreads();
+            if (wave == 0) { w0_fwd(L, KL, k, dl, lane); w0_bwd(L, KL, k, dl, lane); }
+            __syncthreads();
+            for (int j = tid; j < n; j += RT) {
+                double v = -dv[j];
+                for (int a = 0; a < k; ++a) v -= p.CH[(size_t)act[a] * n + j] * dl[a];
+                x[j] += v;
+            }
+            __syncthreads();
+            if (wave == 0) { for (int a = lane; a < k; a += 64) lam[a] += dl[a]; }
+            __syncthreads();
+        }
+
+    // ---- outputs ----------------------------------------------------------------------------------------------------------
+    double* xo = p.x + (size_t)qi * n;
+    for (int j = tid; j < n; j += RT) xo[j] = status == 3 ? 0.0 : x[j] * s.d[j];
+    if (p.z) for (int r = tid; r < m; r += RT) p.z[(size_t)qi * m + r] = 0.0;
+    __syncthreads();
+    if (p.z) for (int a = tid; a < k; a += RT) p.z[(size_t)qi * m + act[a]] = lam[a] / s.rn[act[a]];
+    double part = 0.0;
+    for (int j = tid; j < n; j += RT) {
+        double v = 0.0;
+        for (int i = 0; i < n; ++i) v += s.Ps[(size_t)i * n + j] * x[i];
+        part += x[j] * (0.5 * v + qs[j]);
+    }
+    const double obj = blk_sum(part, red);
+    if (tid == 0) {
+        if (p.obj) p.obj[qi] = obj;
+        if (p.status) p.status[qi] = status;
+        if (p.iters) p.iters[qi] = steps;
+    }
+}
+
+int rows_kl(int n, int m) { return std::max(1, std::min(std::min(n, m), 96)); }
+
+}  // namespace
+
+extern "C" {
+
+long mpcqp_rows_workspace(int n, int m, long* per_instance) {
+    if (n < 1 || m < 1) return 0;
+    const Layout l = make_layout(n, m);
+    if (per_instance) *per_instance = l.stride;
+    return l.nd0 + (long)m * n + (long)m * m;
+}
+
+int mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double* G, double* shared_ws, int* int_ws,
+                     void* stream) {
+    if (n < 1 || m < 1 || !P || !G || !shared_ws || !int_ws) return MPCQP_EINVAL;
+    if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Layout l = make_layout(n, m);
+    int rc = dense_shared_setup_sigma(n, m, P, G, shared_ws, int_ws, 0.0, st);
+    if (rc != MPCQP_OK) return rc;
+    const SharedPtrs s = shared_ptrs(shared_ws, n, m);
+    double* CH = shared_ws + l.nd0;
+    double* Gram = CH + (size_t)m * n;
+    rc = launch_gemm_nt(s.Cs, n, s.Hi, n, CH, n, m, n, n, 1.0, 0.0, st);          // CH = Cs Hi   (Hi symmetric)
+    if (rc != MPCQP_OK) return rc;
+    return launch_gemm_nt(CH, n, s.Cs, n, Gram, m, m, m, n, 1.0, 0.0, st);          // Gram = CH Cs'
+}
+
+int mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, const double* h, double* x, double* z,
+                     double* obj, int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream) {
+    if (batch < 1 || n < 1 || m < 1 || !q || !h || !x || !shared_ws || !instance_ws) return MPCQP_EINVAL;
+    if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const Layout l = make_layout(n, m);
+    const SharedPtrs s = shared_ptrs(shared_ws, n, m);
+    const double* CH = shared_ws + l.nd0;
+    const double* Gram = CH + (size_t)m * n;
+
+    PrepParams pp;
+    pp.q = q; pp.h = h; pp.ws0 = shared_ws; pp.inst = instance_ws; pp.l = l; pp.n = n; pp.m = m; pp.B = batch;
+    const long total = ((long)n + m) * batch;
+    hipLaunchKernelGGL(rows_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, pp);
+    if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+    // xu = -Hi qs ;  res = Cs xu - cs   (both over the whole batch: the shared matrices are read once, not once per QP)
+    int rc = launch_gemm_nt(instance_ws + l.o_qs, l.stride, s.Hi, n, instance_ws + l.o_xu, l.stride, batch, n, n, -1.0, 0.0, st);
+    if (rc != MPCQP_OK) return rc;
+    rc = launch_gemm_nt(instance_ws + l.o_xu, l.stride, s.Cs, n, instance_ws + l.o_res, l.stride, batch, m, n, 1.0, -1.0, st);
+    if (rc != MPCQP_OK) return rc;
+
+    RowsParams r;
+    r.ws0 = shared_ws; r.CH = CH; r.Gram = Gram; r.inst = instance_ws; r.l = l;
+    r.x = x; r.z = z; r.obj = obj; r.status = status; r.iters = iters;
+    r.n = n; r.m = m; r.B = batch; r.KL = rows_kl(n, m); r.max_steps = 20 * (n + m) + 100; r.refine = 2;
+    const size_t lds = ((size_t)r.KL * r.KL + 4 * (size_t)r.KL) * sizeof(double) + (size_t)r.KL * sizeof(int);
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds) != hipSuccess) return MPCQP_EHIP;
+    hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds, st, r);
+    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+}  // extern "C"

@@ -60,6 +60,8 @@ class Planner:
         self.rho = None
         self.info = None
         self._general = None         # state-box / polytopic rows, if any
+        self.general_path = "rows"   # "rows": Gram / constraint-space kernel; "dense": the general dense kernel
+        self.rows_mem_limit = 32 << 30   # bytes of shared workspace (Gram matrix) above which "rows" falls back to "dense"
         self._gen = None             # their condensed form (G, E, h0), built by setup()
         self.no_sync = False         # True: set-up calls never wait for the device (closed loops)
         self.check_inputs = True     # False: skip the host-side sanity checks that synchronise (u_min <= u_max)
@@ -292,6 +294,30 @@ class Planner:
         B, n, m = x0.shape[0], self.n, gen["G"].shape[0]
         q = torch.addmm(gen["f0"].unsqueeze(0), x0, gen["F"].t()).contiguous()        # q = F x0 + f0
         h = (gen["h0"].unsqueeze(0) - x0 @ gen["E"].t()).contiguous()                 # h = h0 - E x0
+        x = torch.empty((B, n), dtype=torch.float64, device=dev)
+        z = torch.zeros((B, max(m, 1)), dtype=torch.float64, device=dev)
+        obj = torch.empty(B, dtype=torch.float64, device=dev)
+        st = torch.empty(B, dtype=torch.int32, device=dev)
+        iters = torch.empty(B, dtype=torch.int32, device=dev)
+        per = C.c_long(0)
+        ns = lib.mpcqp_rows_workspace(n, m, C.byref(per)) if m > 0 else 0
+        if self.general_path == "rows" and m > 0 and 8 * ns <= self.rows_mem_limit:
+            # constraint-space path: Gram matrix of the rows once per model, then (k+1) of its rows per active-set step
+            if gen.get("rows_shared") is None:
+                gen["rows_shared"] = torch.empty(ns, dtype=torch.float64, device=dev)
+                iws = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
+                rc = lib.mpcqp_rows_setup(dev.index or 0, n, m, _ptr(gen["H"]), _ptr(gen["G"]), _ptr(gen["rows_shared"]),
+                                          _ptr(iws), self._stream())
+                if rc != _lib.OK:
+                    raise RuntimeError(f"mpcqp_rows_setup failed with code {rc}")
+            if gen.get("rows_inst") is None or gen["rows_batch"] < B:
+                gen["rows_inst"] = torch.empty(B * per.value, dtype=torch.float64, device=dev)
+                gen["rows_batch"] = B
+            rc = lib.mpcqp_rows_solve(dev.index or 0, B, n, m, _ptr(q), _ptr(h), _ptr(x), _ptr(z), _ptr(obj), _ptr(st),
+                                      _ptr(iters), _ptr(gen["rows_shared"]), _ptr(gen["rows_inst"]), self._stream())
+            if rc != _lib.OK:
+                raise RuntimeError(f"mpcqp_rows_solve failed with code {rc}")
+            return self._general_info(x, z, obj, st, iters, m, want_multipliers)
         ni = C.c_long(0)
         nd = lib.mpcqp_dense_workspace(n, m, 0, C.byref(ni))
         if gen.get("ws") is None or gen["ws_batch"] < B:        # shared set-up: once per model (and per larger batch)
@@ -302,19 +328,18 @@ class Planner:
                                               _ptr(gen["ws"]), _ptr(gen["iws"]), self._stream())
             if rc != _lib.OK:
                 raise RuntimeError(f"mpcqp_dense_shared_setup failed with code {rc}")
-        x = torch.empty((B, n), dtype=torch.float64, device=dev)
-        z = torch.zeros((B, max(m, 1)), dtype=torch.float64, device=dev)
-        obj = torch.empty(B, dtype=torch.float64, device=dev)
-        st = torch.empty(B, dtype=torch.int32, device=dev)
-        iters = torch.empty(B, dtype=torch.int32, device=dev)
         rc = lib.mpcqp_dense_shared_solve(dev.index or 0, B, n, m, 0, _ptr(q), _ptr(h), C.c_void_p(0), _ptr(x), _ptr(z),
                                           C.c_void_p(0), _ptr(obj), _ptr(st), _ptr(iters), _ptr(gen["ws"]), _ptr(gen["iws"]),
                                           self._stream())
         if rc != _lib.OK:
             raise RuntimeError(f"mpcqp_dense_shared_solve failed with code {rc}")
+        return self._general_info(x, z, obj, st, iters, m, want_multipliers)
+
+    def _general_info(self, x, z, obj, st, iters, m, want_multipliers):
         # dense status 0 optimal | 1 step cap | 2 infeasible | 3 numerical  ->  MPCQP_SOLVED | MPCQP_MAX_ITER | 3 | 4
+        B = x.shape[0]
         status = torch.where(st == 0, torch.zeros_like(st), st + 1)
-        self.info = SimpleNamespace(iters=torch.zeros(B, dtype=torch.int32, device=dev), status=status,
+        self.info = SimpleNamespace(iters=torch.zeros(B, dtype=torch.int32, device=self.device), status=status,
                                     obj=obj, prim_res=None, dual_res=None,
                                     polish_steps=iters % 1000, lam=z[:, :m] if want_multipliers else None)
         return x.reshape(B, self.N, self.nu)

@@ -26,8 +26,9 @@ def _oracle_rows(prob):
     return G[keep], E[keep], h0[keep]
 
 
+@pytest.mark.parametrize("path", ["rows", "dense"])
 @pytest.mark.parametrize("N,nx,nu,batch", [(8, 4, 2, 16), (20, 10, 3, 12)])
-def test_state_and_polytope_rows_match_oracle(N, nx, nu, batch):
+def test_state_and_polytope_rows_match_oracle(N, nx, nu, batch, path):
     from mpc_amd.configs import long_horizon
     from mpc_amd.planner import Planner
     from oracle import mpc_oracle as mo
@@ -36,6 +37,7 @@ def test_state_and_polytope_rows_match_oracle(N, nx, nu, batch):
     prob["x0"] *= 1.6                     # far enough out that state and polytope rows bind (some instances infeasible)
     prob["x_max"][0] = np.inf            # a dropped (null) row block
     pl = Planner(nx, nu, N).set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+    pl.general_path = path
     pl.set_constraints(prob["u_min"], prob["u_max"], x_min=prob["x_min"], x_max=prob["x_max"],
                        C=prob["C"], c_min=prob["c_min"], c_max=prob["c_max"])
     U = pl.solve(prob["x0"], want_multipliers=True).cpu().numpy().reshape(batch, -1)
@@ -44,6 +46,7 @@ def test_state_and_polytope_rows_match_oracle(N, nx, nu, batch):
     H, F, f0 = mo.condense(prob)
     G, E, h0 = _oracle_rows(prob)
     assert pl.info.lam.shape[1] == G.shape[0]
+    assert ("rows_shared" in pl._gen) == (path == "rows")
     nbind = 0
     for i in range(batch):
         q = F @ prob["x0"][i] + f0; h = h0 - E @ prob["x0"][i]
@@ -73,6 +76,15 @@ def test_full_horizon_config5_kkt_certificate():
                        C=prob["C"], c_min=prob["c_min"], c_max=prob["c_max"])
     U = pl.solve(prob["x0"], want_multipliers=True).cpu().numpy().reshape(batch, -1)
     st = pl.info.status.cpu().numpy(); z = pl.info.lam.cpu().numpy(); obj = pl.info.obj.cpu().numpy()
+    assert "rows_shared" in pl._gen                      # the default: the constraint-space kernel
+    # the general dense kernel on the same data lands on the same vertex
+    pl.general_path = "dense"
+    Ud = pl.solve(prob["x0"]).cpu().numpy().reshape(batch, -1)
+    std = pl.info.status.cpu().numpy(); objd = pl.info.obj.cpu().numpy()
+    assert (st == std).all()
+    ok = st == 0
+    assert _rel(U[ok], Ud[ok]) <= 1e-8
+    assert np.abs(obj[ok] - objd[ok]).max() <= 1e-9 * np.abs(objd[ok]).max()
     H, F, f0 = mo.condense(prob)
     G, E, h0 = _oracle_rows(prob)
     assert z.shape[1] == G.shape[0] == 13200
