@@ -18,7 +18,7 @@
 // S = Gram[A, A].  The iteration itself is the same Goldfarb-Idnani dual active-set method as dense_qp.hip (same
 // pivoting rules, same thresholds), so both paths land on the same vertex; the tests compare them.
 //
-// Per solve: scale (q, h) -> GEMM xu = -Qs Hi -> GEMM res = Xu Cs' - cs -> one 512-thread workgroup per instance.
+// Per solve: scale (q, h) -> GEMM xu = -Qs Hi -> GEMM res = Xu Cs' - cs -> one 1024-thread workgroup per instance.
 #include "common.h"
 #include <algorithm>
 #include <cstdint>
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(PrepParams p) {
 }
 
 // ---- the active-set iteration, one workgroup per instance ---------------------------------------------------------------
-constexpr int RT = 512;
+constexpr int RT = 1024;
 
 struct RowsParams {
     const double *ws0, *CH, *Gram;
@@ -213,6 +213,39 @@ __device__ void blk_argmax(double v, int idx, double* red, int* redi, double& vo
         if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
     }
     vout = v; iout = idx;
+}
+
+// y = M v for the symmetric n x n matrix M (row-major, read by columns: coalesced), v staged in LDS (vs), all RT threads:
+// RT/128 groups of 128 column lanes split the reduction range, partial sums meet in LDS (part: RT doubles)
+__device__ void blk_symv(double* y, const double* M, const double* v, int n, double* vs, double* part) {
+    const int tid = threadIdx.x, g = tid >> 7, jl = tid & 127;
+    __syncthreads();
+    for (int i = tid; i < n; i += RT) vs[i] = v[i];
+    __syncthreads();
+    const int q = (n + RT / 128 - 1) / (RT / 128), i0 = g * q, i1 = min(n, i0 + q);
+    for (int j0 = 0; j0 < n; j0 += 128) {
+        const int j = j0 + jl;
+        double acc = 0.0;
+        if (j < n) {
+            // every instance reads the same shared matrix: start each one at a different row so that the workgroups of
+            // an XCD do not queue on the same L2 lines at the same time
+            const double* mj = M + j;
+            const int im = i0 + (int)((blockIdx.x * 11u) % (unsigned)max(i1 - i0, 1));
+#pragma unroll 8
+            for (int i = im; i < i1; ++i) acc += mj[(size_t)i * n] * vs[i];
+#pragma unroll 8
+            for (int i = i0; i < im; ++i) acc += mj[(size_t)i * n] * vs[i];
+        }
+        part[tid] = acc;
+        __syncthreads();
+        if (g == 0 && j < n) {
+            double sum = 0.0;
+#pragma unroll
+            for (int e = 0; e < RT / 128; ++e) sum += part[128 * e + jl];
+            y[j] = sum;
+        }
+        __syncthreads();
+    }
 }
 
 // wave 0, vector in LDS: v <- L^-1 v / v <- L^-T v for the k x k lower factor L (leading dimension ld)
@@ -300,12 +333,20 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     double* rv = lv + KL;
     double* lam = rv + KL;
     double* dl = lam + KL;
-    int* act = reinterpret_cast<int*>(dl + KL);
+    double* vs = dl + KL;                                // n: matvec operand
+    double* part = vs + n + (n & 1);                     // RT: matvec partial sums
+    int* act = reinterpret_cast<int*>(part + RT);
     const SharedPtrs s = shared_ptrs(p.ws0, n, m);
     double* c = p.inst + (size_t)qi * p.l.stride;
     double* res = c + p.l.o_res; const double* cs = c + p.l.o_cs; const double* qs = c + p.l.o_qs;
     const double* xu = c + p.l.o_xu; double* x = c + p.l.o_x; double* t1 = c + p.l.o_t1; double* dv = c + p.l.o_dv;
 
+#ifdef ROWS_PROF
+    long long tk0 = wall_clock64(), t_arg = 0, t_dir = 0, t_upd = 0, t_book = 0, tk;
+#define TICK(acc) { tk = wall_clock64(); acc += tk - tk0; tk0 = tk; }
+#else
+#define TICK(acc)
+#endif
     int status = (int)s.W0[1];      // 0 optimal, 1 step cap, 2 infeasible, 3 numerical (P not positive definite, or more than KL rows bind)
     int k = 0, steps = 0;
 
@@ -322,6 +363,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         }
         double v0; int pp;
         blk_argmax(best, bi, red, redi, v0, pp);
+        TICK(t_arg)
         if (pp < 0) break;
         const double* Grow = p.Gram + (size_t)pp * m;
         const double nHn = Grow[pp];
@@ -356,24 +398,26 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                 const double ot = __shfl_xor(tr, o); const int oj = __shfl_xor(jb, o);
                 if (oj >= 0 && (jb < 0 || ot < tr || (ot == tr && oj < jb))) { tr = ot; jb = oj; }
             }
+            TICK(t_dir)
             if (jb < 0 && dep) { status = 2; break; }           // no step possible: infeasible
             const bool full = !dep && t2 <= tr;
             const double t = full ? t2 : tr;
             if (!dep)
-                for (int r0 = 0; r0 < m; r0 += 4 * RT) {
-                    double sv[4]; int r[4];
+                for (int r0 = 0; r0 < m; r0 += 8 * RT) {
+                    double sv[8]; int r[8];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) { r[e] = r0 + e * RT + tid; sv[e] = r[e] < m ? Grow[r[e]] : 0.0; }
+                    for (int e = 0; e < 8; ++e) { r[e] = r0 + e * RT + tid; sv[e] = r[e] < m ? Grow[r[e]] : 0.0; }
                     for (int a = 0; a < k; ++a) {
                         const double cf = rv[a];
                         const double* ga = p.Gram + (size_t)act[a] * m;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) if (r[e] < m) sv[e] -= cf * ga[r[e]];
+                        for (int e = 0; e < 8; ++e) if (r[e] < m) sv[e] -= cf * ga[r[e]];
                     }
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) if (r[e] < m) res[r[e]] -= t * sv[e];
+                    for (int e = 0; e < 8; ++e) if (r[e] < m) res[r[e]] -= t * sv[e];
                 }
             __syncthreads();
+            TICK(t_upd)
             if (wave == 0) {
                 for (int a = lane; a < k; a += 64) lam[a] -= t * rv[a];
                 wave_sync();
@@ -394,9 +438,14 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                 --k;
                 k = rows_rebuild(p.Gram, m, L, KL, act, lam, k, &sflag);
             }
+            TICK(t_book)
         }
     }
     __syncthreads();
+#ifdef ROWS_PROF
+    long long t_fin0 = wall_clock64(), t_x = 0, t_sv = 0, t_nl = 0, t_rows = 0, t_out = 0;
+    tk0 = t_fin0;
+#endif
 
     // ---- x = xu - CH[act,:]' lam, then refinement on the final active set with Ps / Cs themselves ----------------------
     for (int j = tid; j < n; j += RT) {
@@ -405,21 +454,20 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         x[j] = v;
     }
     __syncthreads();
+    TICK(t_x)
     if (status == 0)
         for (int itr = 0; itr < p.refine; ++itr) {
-            for (int j = tid; j < n; j += RT) {             // g = Ps x + qs + N' lam   (Ps symmetric: column reads coalesce)
-                double v = qs[j];
-                for (int i = 0; i < n; ++i) v += s.Ps[(size_t)i * n + j] * x[i];
+            blk_symv(t1, s.Ps, x, n, vs, part);             // g = Ps x + qs + N' lam
+            TICK(t_sv)
+            for (int j = tid; j < n; j += RT) {
+                double v = t1[j] + qs[j];
                 for (int a = 0; a < k; ++a) v += s.Cs[(size_t)act[a] * n + j] * lam[a];
                 t1[j] = v;
             }
             __syncthreads();
-            for (int j = tid; j < n; j += RT) {             // dv = Hi g
-                double v = 0.0;
-                for (int i = 0; i < n; ++i) v += s.Hi[(size_t)i * n + j] * t1[i];
-                dv[j] = v;
-            }
-            __syncthreads();
+            TICK(t_nl)
+            blk_symv(dv, s.Hi, t1, n, vs, part);            // dv = Hi g
+            TICK(t_sv)
             for (int a = wave; a < k; a += RT / 64) {       // N (x - dv) - cs on the active rows
                 const double* na = s.Cs + (size_t)act[a] * n;
                 double v = 0.0;
@@ -438,6 +486,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
             __syncthreads();
             if (wave == 0) { for (int a = lane; a < k; a += 64) lam[a] += dl[a]; }
             __syncthreads();
+            TICK(t_rows)
         }
 
     // ---- outputs ----------------------------------------------------------------------------------------------------------
@@ -446,13 +495,18 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     if (p.z) for (int r = tid; r < m; r += RT) p.z[(size_t)qi * m + r] = 0.0;
     __syncthreads();
     if (p.z) for (int a = tid; a < k; a += RT) p.z[(size_t)qi * m + act[a]] = lam[a] / s.rn[act[a]];
-    double part = 0.0;
-    for (int j = tid; j < n; j += RT) {
-        double v = 0.0;
-        for (int i = 0; i < n; ++i) v += s.Ps[(size_t)i * n + j] * x[i];
-        part += x[j] * (0.5 * v + qs[j]);
-    }
-    const double obj = blk_sum(part, red);
+    __syncthreads();
+    TICK(t_out)
+    blk_symv(t1, s.Ps, x, n, vs, part);
+    TICK(t_sv)
+    double po = 0.0;
+    for (int j = tid; j < n; j += RT) po += x[j] * (0.5 * t1[j] + qs[j]);
+    const double obj = blk_sum(po, red);
+#ifdef ROWS_PROF
+    if (tid == 0 && (qi & 63) == 0)
+        printf("qp %d steps %d k %d: argmax %lld dir %lld update %lld book %lld final %lld = x %lld symv %lld nl %lld rows %lld out %lld (x10 ns)\n",
+               qi, steps, k, t_arg, t_dir, t_upd, t_book, wall_clock64() - t_fin0, t_x, t_sv, t_nl, t_rows, t_out);
+#endif
     if (tid == 0) {
         if (p.obj) p.obj[qi] = obj;
         if (p.status) p.status[qi] = status;
@@ -513,8 +567,10 @@ int mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, co
     RowsParams r;
     r.ws0 = shared_ws; r.CH = CH; r.Gram = Gram; r.inst = instance_ws; r.l = l;
     r.x = x; r.z = z; r.obj = obj; r.status = status; r.iters = iters;
-    r.n = n; r.m = m; r.B = batch; r.KL = rows_kl(n, m); r.max_steps = 20 * (n + m) + 100; r.refine = 2;
-    const size_t lds = ((size_t)r.KL * r.KL + 4 * (size_t)r.KL) * sizeof(double) + (size_t)r.KL * sizeof(int);
+    r.n = n; r.m = m; r.B = batch; r.KL = rows_kl(n, m); r.max_steps = 20 * (n + m) + 100;
+    r.refine = 1;       // Hi is the exact-arithmetic inverse here (no proximal term): one round squares its rounding error
+    const size_t lds = ((size_t)r.KL * r.KL + 4 * (size_t)r.KL + n + (n & 1) + RT) * sizeof(double) + (size_t)r.KL * sizeof(int);
+    if (lds > 160 * 1024) return MPCQP_ENOTIMPL;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)lds) != hipSuccess) return MPCQP_EHIP;
     hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds, st, r);
