@@ -97,6 +97,38 @@ class ClosedLoopLTV:
         return dict(xbar=xbar, A=A, B=Bm, xr=(x_ref - xbar[:, 1:]).contiguous(), ur=(-ubar).contiguous(),
                     lb=(self.u_min - ubar).contiguous(), ub=(self.u_max - ubar).contiguous())
 
+    def capture(self, x, x_ref, warm=True, **opts):
+        """Record one closed-loop step (linearise -> assemble -> factor -> solve -> apply -> shift) into a HIP graph.
+        Call after at least two eager step()s (buffers registered, set-up calls asynchronous, workspaces grown).
+        Afterwards ``replay(x, x_ref)`` runs the whole step with one graph launch and no host work in between."""
+        if not (self._registered and self.pl.no_sync):
+            raise RuntimeError("capture() needs two eager step() calls first")
+        self._gx, self._gxr = x.clone(), x_ref.clone()
+        self._gu0 = torch.empty((x.shape[0], self.model.nu), dtype=torch.float64, device=self.device)
+        torch.cuda.synchronize(self.device)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph, capture_error_mode="relaxed"):
+            self._step_in_place(self._gx, self._gxr, warm, opts)
+        return self
+
+    def replay(self, x, x_ref):
+        """One recorded step on new data; returns the applied input (B,nu) (a persistent buffer: copy to keep)."""
+        self._gx.copy_(x); self._gxr.copy_(x_ref)
+        self._graph.replay()
+        return self._gu0
+
+    def _step_in_place(self, x, x_ref, warm, opts):
+        # the same step as step() with every result in persistent buffers (graph replays read and write fixed addresses)
+        ubar = self.plan
+        self.linearize(x, ubar, x_ref)
+        pl = self.pl
+        pl.refresh()
+        dU = pl.solve(self._dx0, warm_start=warm, **opts)
+        plan = ubar + dU
+        self._gu0.copy_(plan[:, 0])
+        ubar[:, :-1].copy_(plan[:, 1:]); ubar[:, -1].copy_(plan[:, -1])
+        pl.shift().recenter()
+
     def step(self, x, x_ref, warm=True, **opts):
         """x (B,nx) current states, x_ref (B,N,nx) references for x_1..x_N.  Returns the applied input (B,nu)."""
         Bn = x.shape[0]

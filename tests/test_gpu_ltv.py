@@ -126,3 +126,43 @@ def test_bicycle_closed_loop_matches_oracle_and_converges():
     assert ((x[:, 3] - cfg["v_ref"]).abs() < 0.2).all()
     # the shifted multipliers are a useful guess: late steps need (almost) no active-set changes
     assert np.mean(steps_used[-10:]) <= 1.0
+
+
+def test_closed_loop_graph_replay_matches_eager_steps():
+    """One closed-loop step recorded as a HIP graph (linearise -> assemble -> factor -> solve -> apply -> shift, no host
+    work in between) drives the rollouts exactly like the eager step() does."""
+    import torch
+    from mpc_amd.configs import make_config
+    from mpc_amd.ltv import Bicycle, ClosedLoopLTV
+    cfg = make_config(4, batch=64, seed=7)
+    N, dt, L = cfg["N"], cfg["dt"], cfg["L"]
+    dev = torch.device("cuda:0")
+    ks = torch.arange(1, N + 1, device=dev, dtype=torch.float64)
+
+    def ref_of(x):
+        x_ref = torch.zeros((x.shape[0], N, 4), dtype=torch.float64, device=dev)
+        x_ref[:, :, 0] = x[:, :1] + cfg["v_ref"] * dt * ks
+        x_ref[:, :, 3] = cfg["v_ref"]
+        return x_ref
+
+    def run(graph_after):
+        loop = ClosedLoopLTV(Bicycle(L, dt), N, cfg["Q"], cfg["R"], cfg["P"], cfg["u_min"], cfg["u_max"], device=dev)
+        x = torch.as_tensor(cfg["x0"], device=dev)
+        us = []
+        for it in range(12):
+            x_ref = ref_of(x)
+            if graph_after is not None and it == graph_after:
+                loop.capture(x, x_ref)
+            if graph_after is not None and it >= graph_after:
+                u0 = loop.replay(x, x_ref).clone()
+            else:
+                u0 = loop.step(x, x_ref)
+            assert (loop.pl.info.status == 0).all(), it
+            us.append(u0.cpu().numpy())
+            x = loop.model.step(x, u0)
+        return np.array(us), x.cpu().numpy()
+
+    u_eager, x_eager = run(None)
+    u_graph, x_graph = run(4)
+    assert np.abs(u_eager - u_graph).max() <= 1e-12
+    assert np.abs(x_eager - x_graph).max() <= 1e-12
