@@ -182,8 +182,9 @@ int  mpcqp_dense_shared_solve(int device_id, int batch, int n, int m, int p, con
  * configs[4], 13,200 rows x 600 variables; rows as in LaunchPlannerQPFormulation.py:109-114, Launch3DPlanner.py:134-142):
  * the set-up additionally forms CH = Cs Hi (m x n) and the dual Hessian Cs Hi Cs' (m x m), and each solve keeps the row
  * residuals up to date through rows of that matrix instead of re-evaluating G x.  Needs P positive definite (the
- * condensed MPC Hessian is: Rbar > 0) and inequality rows only; at most 96 rows may be active at once (status 3
- * beyond).  Same outputs and status codes as mpcqp_solve_dense; iters = active-set steps.
+ * condensed MPC Hessian is: Rbar > 0) and inequality rows only; at most 176 rows may be active at once (status 3
+ * beyond; instances with more than 96 finish in a second launch).  Same outputs and status codes as mpcqp_solve_dense
+ * (`status` is required here); iters = active-set steps.
  * shared_ws: mpcqp_rows_workspace(n, m, &per) doubles, written by the set-up, read-only afterwards;
  * int_ws: n ints (set-up only); instance_ws: batch * per doubles. */
 long mpcqp_rows_workspace(int n, int m, long* per_instance);

@@ -13,16 +13,21 @@
 // contraction Gamma'(Qbar Gamma) on v_mfma_f64_16x16x4_f64, lower tiles only and mirrored, with
 // the all-zero leading k-steps of the block-lower-triangular Gamma skipped.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
 struct AsmParams {
     const double *A, *B, *Q, *R, *P, *xref, *uref;
-    int rows_in_lds;
+    int rows_in_lds, ab_in_lds;
     long xref_stride, uref_stride;       // doubles between the references of consecutive models (0: shared)
     double *Gam, *QG, *Phi, *H, *F, *f0;
     int nx, nu, N, n, p, tv;
 };
+
+// barrier that orders LDS traffic only: the rollout's global stores (Gamma, Qbar Gamma, Phi rows) stay in flight across
+// it -- nothing reads them back before the full barrier that ends the rollout
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -42,53 +47,72 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     // themselves in global memory -- block k-1 is complete and visible to the workgroup when block k reads it
     double* rowP = reinterpret_cast<double*>(smem);     // 2 x (nx, nx)
     double* rowG = rowP + 2 * nx * nx;                  // 2 x (nx, n) ping-pong
+    double* sQ = rowG + (a.rows_in_lds ? 2 * nx * n : 0);   // Q, P (nx, nx) each
+    double* sA = sQ + 2 * nx * nx;                      // the model's A_k, B_k (a.ab_in_lds): the rollout is a chain of
+    double* sB = sA + (a.tv ? N : 1) * nx * nx;         // N dependent steps, so nothing in it should wait on global memory
     const int tid = threadIdx.x;
+    for (int i = tid; i < nx * nx; i += 256) { sQ[i] = a.Q[i]; sQ[nx * nx + i] = a.P[i]; }
+    if (a.ab_in_lds) {
+        for (int i = tid; i < (int)strideA; i += 256) sA[i] = Am[i];
+        for (int i = tid; i < (int)strideB; i += 256) sB[i] = Bm[i];
+    }
 
+#ifdef ASM_PROF
+    long long c0 = wall_clock64();
+#endif
     // ---- phase 1: rollout --------------------------------------------------------------
     if (a.rows_in_lds) for (int i = tid; i < nx * n; i += 256) rowG[i] = 0.0;
     for (int i = tid; i < nx * nx; i += 256) rowP[i] = (i / nx == i % nx) ? 1.0 : 0.0;
     __syncthreads();
+    // (row, column) of this thread's first element in the (nx, n) and (nx, nx) blocks, advanced by 256 elements per trip:
+    // no integer division inside the N-step chain
+    const int rg0 = tid / n, cg0 = tid % n, dgr = 256 / n, dgc = 256 % n;
+    const int rp0 = tid / nx, cp0 = tid % nx, dpr = 256 / nx, dpc = 256 % nx;
     for (int k = 0; k < N; ++k) {
-        const double* Ak = Am + (a.tv ? (size_t)k * nx * nx : 0);
-        const double* Bk = Bm + (a.tv ? (size_t)k * nx * nu : 0);
-        const double* Qk = (k == N - 1) ? a.P : a.Q;
+        const double* Ak = (a.ab_in_lds ? sA : Am) + (a.tv ? (size_t)k * nx * nx : 0);
+        const double* Bk = (a.ab_in_lds ? sB : Bm) + (a.tv ? (size_t)k * nx * nu : 0);
+        const double* Qk = (k == N - 1) ? sQ + nx * nx : sQ;
         const double* gin = a.rows_in_lds ? rowG + (k & 1) * nx * n : Gam + (size_t)(k > 0 ? k - 1 : 0) * nx * n;
         double* gout = a.rows_in_lds ? rowG + ((k + 1) & 1) * nx * n : Gam + (size_t)k * nx * n;
         const double* pin = rowP + (k & 1) * nx * nx;
         double* pout = rowP + ((k + 1) & 1) * nx * nx;
-        for (int i = tid; i < nx * n; i += 256) {
-            const int r = i / n, c = i % n;
+        const int cB = k * nu;                          // first column of stage k
+        for (int i = tid, r = rg0, c = cg0; i < nx * n; i += 256) {
             double s = 0.0;
-            const int stage = c / nu;
-            if (stage < k) {
+            if (c < cB) {
                 for (int j = 0; j < nx; ++j) s += Ak[r * nx + j] * gin[j * n + c];
-            } else if (stage == k) {
-                s = Bk[r * nu + (c - k * nu)];
+            } else if (c < cB + nu) {
+                s = Bk[r * nu + (c - cB)];
             }
             gout[i] = s;
             if (a.rows_in_lds) Gam[(size_t)(k * nx + r) * n + c] = s;
+            r += dgr; c += dgc;
+            if (c >= n) { c -= n; ++r; }
         }
-        for (int i = tid; i < nx * nx; i += 256) {
-            const int r = i / nx, c = i % nx;
+        for (int i = tid, r = rp0, c = cp0; i < nx * nx; i += 256) {
             double s = 0.0;
             for (int j = 0; j < nx; ++j) s += Ak[r * nx + j] * pin[j * nx + c];
             pout[i] = s;
             Phi[(size_t)(k * nx + r) * nx + c] = s;
+            r += dpr; c += dpc;
+            if (c >= nx) { c -= nx; ++r; }
         }
-        __threadfence_block();
-        __syncthreads();
-        for (int i = tid; i < nx * n; i += 256) {
-            const int r = i / n, c = i % n;
+        if (a.rows_in_lds) lds_barrier(); else { __threadfence_block(); __syncthreads(); }
+        for (int i = tid, r = rg0, c = cg0; i < nx * n; i += 256) {
             double s = 0.0;
             for (int j = 0; j < nx; ++j) s += Qk[r * nx + j] * gout[j * n + c];
             QG[(size_t)(k * nx + r) * n + c] = s;
+            r += dgr; c += dgc;
+            if (c >= n) { c -= n; ++r; }
         }
-        __threadfence_block();
-        __syncthreads();
+        if (a.rows_in_lds) lds_barrier(); else { __threadfence_block(); __syncthreads(); }
     }
     __threadfence_block();
     __syncthreads();
 
+#ifdef ASM_PROF
+    long long c1 = wall_clock64();
+#endif
     // ---- phase 2: H = Gam' QG + Rbar on fp64 MFMA, lower tiles, mirrored ----------------------
     const int lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -124,6 +148,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
             }
         }
 
+#ifdef ASM_PROF
+    __syncthreads();
+    long long c2 = wall_clock64();
+#endif
     // ---- phase 3: F = QG' Phi (n, nx) and f0 = -QG' xr - Rbar ur --------------------------------
     {
         const int NXT = (nx + 15) / 16;
@@ -146,17 +174,35 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
                 if (i < n && j < nx) F[(size_t)i * nx + j] = acc[r4];
             }
         }
-        for (int i = tid; i < n; i += 256) {
+        // f0: wave w sums its quarter of the rows, the quarters meet in LDS (the row buffers of the rollout are free now)
+        __syncthreads();
+        double* part = reinterpret_cast<double*>(smem);         // 4 x 64
+        const int pq = (p + 3) / 4, r0 = wave * pq, r1 = min(p, r0 + pq);
+        for (int i0 = 0; i0 < n; i0 += 64) {
+            const int i = i0 + lane;
             double s = 0.0;
-            if (a.xref)
-                for (int r = 0; r < p; ++r) s -= QG[(size_t)r * n + i] * a.xref[(size_t)m * a.xref_stride + r];
-            if (a.uref) {
-                const int st = i / nu;
-                for (int j = 0; j < nu; ++j) s -= a.R[(i % nu) * nu + j] * a.uref[(size_t)m * a.uref_stride + st * nu + j];
+            if (i < n && a.xref) {
+                const double* xr = a.xref + (size_t)m * a.xref_stride;
+#pragma unroll 4
+                for (int r = r0; r < r1; ++r) s -= QG[(size_t)r * n + i] * xr[r];
             }
-            f0[i] = s;
+            part[wave * 64 + lane] = s;
+            __syncthreads();
+            if (wave == 0 && i < n) {
+                s = part[lane] + part[64 + lane] + part[128 + lane] + part[192 + lane];
+                if (a.uref) {
+                    const int st = i / nu;
+                    for (int j = 0; j < nu; ++j) s -= a.R[(i % nu) * nu + j] * a.uref[(size_t)m * a.uref_stride + st * nu + j];
+                }
+                f0[i] = s;
+            }
+            __syncthreads();
         }
     }
+#ifdef ASM_PROF
+    __syncthreads();
+    if (tid == 0 && (m % 2048) == 0) printf("model %d: rollout %lld H %lld F/f0 %lld (x10 ns)\n", m, c1 - c0, c2 - c1, wall_clock64() - c2);
+#endif
 }
 
 }  // namespace
@@ -167,9 +213,15 @@ int launch_assemble(mpcqp_handle h, hipStream_t st) {
     a.xref_stride = h->xref_stride; a.uref_stride = h->uref_stride;
     a.Gam = h->Gam; a.QG = h->QG; a.Phi = h->Phi; a.H = h->H; a.F = h->F; a.f0 = h->f0;
     a.nx = h->dims.nx; a.nu = h->dims.nu; a.N = h->dims.N; a.n = h->n; a.p = h->p; a.tv = h->dims.time_varying;
-    size_t lds = (size_t)(2 * a.nx * a.n + 2 * a.nx * a.nx) * sizeof(double);
-    a.rows_in_lds = lds <= 160 * 1024;
-    if (!a.rows_in_lds) lds = (size_t)(2 * a.nx * a.nx) * sizeof(double);
+    const size_t fixed = (size_t)(4 * a.nx * a.nx) * sizeof(double);        // Phi ping-pong + Q, P
+    const size_t rows = (size_t)(2 * a.nx * a.n) * sizeof(double);
+    const size_t ab = (size_t)(a.tv ? a.N : 1) * a.nx * (a.nx + a.nu) * sizeof(double);
+    a.rows_in_lds = fixed + rows <= 160 * 1024;
+    size_t lds = fixed + (a.rows_in_lds ? rows : 0);
+    // the staged model is only worth LDS that does not cost occupancy (many small models) or that is tiny
+    a.ab_in_lds = lds + ab <= (h->dims.n_models > 1 ? 16 * 1024 : 160 * 1024);
+    if (a.ab_in_lds) lds += ab;
+    lds = std::max<size_t>(lds, 256 * sizeof(double));                     // the f0 partial sums reuse the front of it
     if (lds > 160 * 1024) { h->err = "assemble: nx too large for the LDS buffers"; return MPCQP_ENOTIMPL; }
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -126,8 +126,12 @@ struct Layout {
     // shared block: [dense set-up of "QP 0" | CH | Gram]
     long nd0;
     // per-instance block
-    long o_res, o_cs, o_qs, o_xu, o_x, o_t1, o_dv, stride;
+    long o_res, o_cs, o_qs, o_xu, o_x, o_t1, o_dv, o_slam, o_sact, stride;      // slam/sact: active set handed to pass 2
 };
+
+// capacity of the active set: first pass (several workgroups per CU), second pass (one per CU, the LDS nearly full)
+int rows_kl1(int n, int m) { return std::max(1, std::min(std::min(n, m), 96)); }
+int rows_kl2(int n, int m) { return std::max(1, std::min(std::min(n, m), 176)); }
 
 Layout make_layout(int n, int m) {
     Layout l;
@@ -135,7 +139,10 @@ Layout make_layout(int n, int m) {
     l.nd0 += l.nd0 & 1;
     const long me = m + (m & 1), ne = n + (n & 1);
     l.o_res = 0; l.o_cs = me; l.o_qs = 2 * me; l.o_xu = l.o_qs + ne; l.o_x = l.o_xu + ne; l.o_t1 = l.o_x + ne; l.o_dv = l.o_t1 + ne;
-    l.stride = l.o_dv + ne;
+    const long K2 = rows_kl2(n, m) + 3;
+    l.o_slam = l.o_dv + ne; l.o_sact = l.o_slam + K2 + (K2 & 1);
+    l.stride = l.o_sact + (K2 + 1) / 2 + 1;
+    l.stride += l.stride & 1;
     return l;
 }
 
@@ -178,7 +185,7 @@ struct RowsParams {
     Layout l;
     double *x, *z, *obj;
     int *status, *iters;
-    int n, m, B, KL, max_steps, refine;
+    int n, m, B, KL, max_steps, refine, pass;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -248,23 +255,26 @@ __device__ void blk_symv(double* y, const double* M, const double* v, int n, dou
     }
 }
 
-// wave 0, vector in LDS: v <- L^-1 v / v <- L^-T v for the k x k lower factor L (leading dimension ld)
-__device__ void w0_fwd(const double* L, int ld, int k, double* v, int lane) {
+// the Cholesky factor of S is stored packed: row i holds its i+1 entries at LIX(i, 0)
+#define LIX(i, j) ((i) * ((i) + 1) / 2 + (j))
+
+// wave 0, vector in LDS: v <- L^-1 v / v <- L^-T v for the k x k lower factor L (packed)
+__device__ void w0_fwd(const double* L, int k, double* v, int lane) {
     for (int c = 0; c < k; ++c) {
-        const double yc = v[c] / L[c * ld + c];
+        const double yc = v[c] / L[LIX(c, c)];
         wave_sync();
         if (lane == 0) v[c] = yc;
-        for (int i = c + 1 + lane; i < k; i += 64) v[i] -= L[i * ld + c] * yc;
+        for (int i = c + 1 + lane; i < k; i += 64) v[i] -= L[LIX(i, c)] * yc;
         wave_sync();
     }
 }
 
-__device__ void w0_bwd(const double* L, int ld, int k, double* v, int lane) {
+__device__ void w0_bwd(const double* L, int k, double* v, int lane) {
     for (int c = k - 1; c >= 0; --c) {
-        const double yc = v[c] / L[c * ld + c];
+        const double yc = v[c] / L[LIX(c, c)];
         wave_sync();
         if (lane == 0) v[c] = yc;
-        for (int i = lane; i < c; i += 64) v[i] -= L[c * ld + i] * yc;
+        for (int i = lane; i < c; i += 64) v[i] -= L[LIX(c, i)] * yc;
         wave_sync();
     }
 }
@@ -283,30 +293,30 @@ __device__ void w0_remove(int* act, double* lam, int j, int k, int lane) {
 
 // L <- chol(Gram[act, act]); a member whose pivot falls below 1e-12 of its diagonal is dependent on the ones before
 // it and is removed.  Returns the (possibly reduced) k.
-__device__ int rows_rebuild(const double* Gram, int m, double* L, int KL, int* act, double* lam, int k, int* sflag) {
+__device__ int rows_rebuild(const double* Gram, int m, double* L, int* act, double* lam, int k, int* sflag) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (;;) {
         __syncthreads();
         for (int idx = tid; idx < k * k; idx += RT) {
             const int a = idx / k, c = idx % k;
-            if (c <= a) L[a * KL + c] = Gram[(size_t)act[a] * m + act[c]];
+            if (c <= a) L[LIX(a, c)] = Gram[(size_t)act[a] * m + act[c]];
         }
         __syncthreads();
         if (wave == 0) {
             int bad = -1;
             for (int j = 0; j < k; ++j) {
-                const double dj = L[j * KL + j];
+                const double dj = L[LIX(j, j)];
                 const double d0 = Gram[(size_t)act[j] * m + act[j]];
                 if (!(dj > 1e-12 * d0)) { bad = j; break; }
                 const double sj = sqrt(dj), inv = 1.0 / sj;
                 wave_sync();
-                if (lane == 0) L[j * KL + j] = sj;
-                for (int i = j + 1 + lane; i < k; i += 64) L[i * KL + j] *= inv;
+                if (lane == 0) L[LIX(j, j)] = sj;
+                for (int i = j + 1 + lane; i < k; i += 64) L[LIX(i, j)] *= inv;
                 wave_sync();
                 const int rem = k - j - 1;
                 for (int idx = lane; idx < rem * rem; idx += 64) {
                     const int i = j + 1 + idx / rem, c = j + 1 + idx % rem;
-                    if (c <= i) L[i * KL + c] -= L[i * KL + j] * L[c * KL + j];
+                    if (c <= i) L[LIX(i, c)] -= L[LIX(i, j)] * L[LIX(c, j)];
                 }
                 wave_sync();
             }
@@ -328,8 +338,8 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     __shared__ int sflag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = p.n, m = p.m, KL = p.KL, qi = blockIdx.x;
-    double* L = reinterpret_cast<double*>(smem);        // KL x KL: lower Cholesky factor of S = Gram[act, act]
-    double* lv = L + (size_t)KL * KL;
+    double* L = reinterpret_cast<double*>(smem);        // packed lower Cholesky factor of S = Gram[act, act], up to KL rows
+    double* lv = L + (size_t)KL * (KL + 1) / 2 + (((size_t)KL * (KL + 1) / 2) & 1);
     double* rv = lv + KL;
     double* lam = rv + KL;
     double* dl = lam + KL;
@@ -349,6 +359,16 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
 #endif
     int status = (int)s.W0[1];      // 0 optimal, 1 step cap, 2 infeasible, 3 numerical (P not positive definite, or more than KL rows bind)
     int k = 0, steps = 0;
+    // hand-over between the passes: sact[0] = members saved by pass 1 (-1: none), sact[1] = its step count, sact[2..] = rows
+    double* slam = c + p.l.o_slam;
+    int* sact = reinterpret_cast<int*>(c + p.l.o_sact);
+    bool handed_over = false;
+    if (p.pass == 2) {
+        if (status != 0 || p.status[qi] != 3 || sact[0] < 0) return;       // uniform over the workgroup
+        k = sact[0]; steps = sact[1];
+        for (int a = tid; a < k; a += RT) { act[a] = sact[2 + a]; lam[a] = slam[a]; }
+        k = rows_rebuild(p.Gram, m, L, act, lam, k, &sflag);
+    }
 
     while (status == 0) {
         // the most violated row that is not in the active set
@@ -375,10 +395,10 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
             for (int a = tid; a < k; a += RT) lv[a] = Grow[act[a]];
             __syncthreads();
             if (wave == 0) {
-                w0_fwd(L, KL, k, lv, lane);
+                w0_fwd(L, k, lv, lane);
                 for (int a = lane; a < k; a += 64) rv[a] = lv[a];
                 wave_sync();
-                w0_bwd(L, KL, k, rv, lane);
+                w0_bwd(L, k, rv, lane);
             }
             __syncthreads();
             // every wave evaluates the step lengths redundantly (k <= KL): identical arithmetic, uniform control flow
@@ -424,10 +444,19 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
             }
             accl += t;
             if (full) {
-                if (k >= KL) { status = 3; break; }
+                if (k >= KL) {
+                    status = 3;
+                    if (p.pass == 1) {      // the active set, with the member that did not fit, goes to the second pass
+                        __syncthreads();
+                        for (int a = tid; a < k; a += RT) { sact[2 + a] = act[a]; slam[a] = lam[a]; }
+                        if (tid == 0) { sact[2 + k] = pp; slam[k] = accl; sact[0] = k + 1; sact[1] = steps; }
+                        handed_over = true;
+                    }
+                    break;
+                }
                 if (wave == 0) {
-                    for (int a = lane; a < k; a += 64) L[k * KL + a] = lv[a];
-                    if (lane == 0) { L[k * KL + k] = sqrt(d2); act[k] = pp; lam[k] = accl; }
+                    for (int a = lane; a < k; a += 64) L[LIX(k, a)] = lv[a];
+                    if (lane == 0) { L[LIX(k, k)] = sqrt(d2); act[k] = pp; lam[k] = accl; }
                 }
                 ++k;
                 added = true;
@@ -436,7 +465,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                 if (!dep) v0 -= t * d2;
                 if (wave == 0) w0_remove(act, lam, jb, k, lane);
                 --k;
-                k = rows_rebuild(p.Gram, m, L, KL, act, lam, k, &sflag);
+                k = rows_rebuild(p.Gram, m, L, act, lam, k, &sflag);
             }
             TICK(t_book)
         }
@@ -476,7 +505,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                 if (lane == 0) dl[a] = v - cs[act[a]];
             }
             __syncthreads();
-            if (wave == 0) { w0_fwd(L, KL, k, dl, lane); w0_bwd(L, KL, k, dl, lane); }
+            if (wave == 0) { w0_fwd(L, k, dl, lane); w0_bwd(L, k, dl, lane); }
             __syncthreads();
             for (int j = tid; j < n; j += RT) {
                 double v = -dv[j];
@@ -508,13 +537,12 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                qi, steps, k, t_arg, t_dir, t_upd, t_book, wall_clock64() - t_fin0, t_x, t_sv, t_nl, t_rows, t_out);
 #endif
     if (tid == 0) {
+        if (!handed_over) sact[0] = -1;
         if (p.obj) p.obj[qi] = obj;
         if (p.status) p.status[qi] = status;
         if (p.iters) p.iters[qi] = steps;
     }
 }
-
-int rows_kl(int n, int m) { return std::max(1, std::min(std::min(n, m), 96)); }
 
 }  // namespace
 
@@ -545,7 +573,7 @@ int mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double*
 
 int mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, const double* h, double* x, double* z,
                      double* obj, int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream) {
-    if (batch < 1 || n < 1 || m < 1 || !q || !h || !x || !shared_ws || !instance_ws) return MPCQP_EINVAL;
+    if (batch < 1 || n < 1 || m < 1 || !q || !h || !x || !status || !shared_ws || !instance_ws) return MPCQP_EINVAL;
     if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Layout l = make_layout(n, m);
@@ -567,13 +595,25 @@ int mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, co
     RowsParams r;
     r.ws0 = shared_ws; r.CH = CH; r.Gram = Gram; r.inst = instance_ws; r.l = l;
     r.x = x; r.z = z; r.obj = obj; r.status = status; r.iters = iters;
-    r.n = n; r.m = m; r.B = batch; r.KL = rows_kl(n, m); r.max_steps = 20 * (n + m) + 100;
+    r.n = n; r.m = m; r.B = batch; r.max_steps = 20 * (n + m) + 100;
     r.refine = 1;       // Hi is the exact-arithmetic inverse here (no proximal term): one round squares its rounding error
-    const size_t lds = ((size_t)r.KL * r.KL + 4 * (size_t)r.KL + n + (n & 1) + RT) * sizeof(double) + (size_t)r.KL * sizeof(int);
-    if (lds > 160 * 1024) return MPCQP_ENOTIMPL;
+    auto lds_of = [&](int KL) {
+        const size_t tri = (size_t)KL * (KL + 1) / 2;
+        return (tri + (tri & 1) + 4 * (size_t)KL + n + (n & 1) + RT) * sizeof(double) + (size_t)KL * sizeof(int);
+    };
+    const int KL1 = rows_kl1(n, m), KL2 = rows_kl2(n, m);
+    const size_t lds1 = lds_of(KL1), lds2 = lds_of(KL2);
+    if (lds1 > 160 * 1024) return MPCQP_ENOTIMPL;
+    const bool second = KL2 > KL1 && lds2 <= 160 * 1024;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds) != hipSuccess) return MPCQP_EHIP;
-    hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds, st, r);
+                            (int)(second ? lds2 : lds1)) != hipSuccess) return MPCQP_EHIP;
+    r.KL = KL1; r.pass = 1;
+    hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds1, st, r);
+    if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+    if (second) {       // instances whose active set outgrew the first pass continue where they stopped; the others return at once
+        r.KL = KL2; r.pass = 2;
+        hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds2, st, r);
+    }
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
 }
 

@@ -301,7 +301,7 @@ class Planner:
         iters = torch.empty(B, dtype=torch.int32, device=dev)
         per = C.c_long(0)
         ns = lib.mpcqp_rows_workspace(n, m, C.byref(per)) if m > 0 else 0
-        if self.general_path == "rows" and m > 0 and 8 * ns <= self.rows_mem_limit:
+        if self.general_path == "rows" and self._general is not None and m > 0 and 8 * ns <= self.rows_mem_limit:
             # constraint-space path: Gram matrix of the rows once per model, then (k+1) of its rows per active-set step
             if gen.get("rows_shared") is None:
                 gen["rows_shared"] = torch.empty(ns, dtype=torch.float64, device=dev)

@@ -98,3 +98,28 @@ def test_full_horizon_config5_kkt_certificate():
         assert abs(z[i] @ (G @ U[i] - h)) <= 1e-8 * scale                         # complementarity
         assert abs(obj[i] - (0.5 * U[i] @ H @ U[i] + q @ U[i])) <= 1e-8 * max(1.0, abs(obj[i]))
         assert (z[i] > 0).sum() > 0
+
+
+def test_rows_path_second_pass_beyond_96_active_rows():
+    """More than 96 rows bind (saturated inputs over most of a 40-step horizon): the constraint-space kernel hands the
+    instance to its second pass (capacity 176) and still lands where the general dense kernel does."""
+    from mpc_amd.configs import long_horizon
+    from mpc_amd.planner import Planner
+    batch, N, nx, nu = 6, 40, 10, 4
+    prob = long_horizon(batch=batch, seed=2, N=N, nx=nx, nu=nu)
+    prob["u_min"] = prob["u_min"] * 0.02; prob["u_max"] = prob["u_max"] * 0.02
+    prob["x_min"] = prob["x_min"] * 50; prob["x_max"] = prob["x_max"] * 50
+    prob["c_min"] = prob["c_min"] * 50; prob["c_max"] = prob["c_max"] * 50
+    out = {}
+    for path in ("rows", "dense"):
+        pl = Planner(nx, nu, N).set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+        pl.general_path = path
+        pl.set_constraints(prob["u_min"], prob["u_max"], x_min=prob["x_min"], x_max=prob["x_max"],
+                           C=prob["C"], c_min=prob["c_min"], c_max=prob["c_max"])
+        U = pl.solve(prob["x0"], want_multipliers=True).cpu().numpy().reshape(batch, -1)
+        out[path] = (U, pl.info.status.cpu().numpy(), pl.info.obj.cpu().numpy(), (pl.info.lam > 0).sum(1).cpu().numpy())
+    U, st, obj, nact = out["rows"]; Ud, std, objd, nactd = out["dense"]
+    assert (st == 0).all() and (std == 0).all()
+    assert nact.max() > 96 and (nact == nactd).all()
+    assert _rel(U, Ud) <= 1e-8
+    assert np.abs(obj - objd).max() <= 1e-9 * np.abs(objd).max()
