@@ -268,26 +268,85 @@ __global__ __launch_bounds__(256) void factor_batch_kernel(FacBatchParams f) {
     }
 }
 
-// n <= 64: one WAVE per model, lane i owns row i, no workgroup barriers (the 256-thread kernel above spends its
-// time in ~200 barriers per model).  LDS per wave: L, L^-1, Hi, each n x (n+1).
+// n <= 64: one WAVE per model, no workgroup barriers (the 256-thread kernel above spends its time in ~200 barriers per
+// model).  Blocked right-looking Cholesky on 16 x 16 tiles: the diagonal tile is factored and inverted in REGISTERS
+// (lane r owns row r, v_readlane broadcasts), every off-diagonal product -- panel L_ib = S_ib T_bb', trailing update
+// S_ij -= L_ib L_jb', T = L^-1 by block back-substitution, Hi = T'T -- is a v_mfma_f64_16x16x4_f64 tile product with
+// operands read once from LDS.  LDS per wave: two (16 nb) x (16 nb + 1) matrices.
 __device__ __forceinline__ void wv_sync() {
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     __builtin_amdgcn_wave_barrier();
 }
 
+template <int SRC>
+__device__ __forceinline__ double readlane_d(double v) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), SRC);
+    return __hiloint2double(hi, lo);
+}
+
+template <int J>
+struct DiagStep {
+    // column J of the tile's Cholesky factor and the rank-1 update of the columns right of it
+    static __device__ __forceinline__ void run(double (&a)[16], double (&dinv)[16], int r, bool& bad) {
+        const double piv = readlane_d<J>(a[J]);
+        if (!(piv > 0.0)) bad = true;
+        const double rs = piv > 0.0 ? 1.0 / sqrt(piv) : 1.0;
+        dinv[J] = rs;
+        a[J] = r < J ? 0.0 : (r == J ? piv * rs : a[J] * rs);
+        update<J + 1>(a);
+        DiagStep<J + 1>::run(a, dinv, r, bad);
+    }
+    template <int C>
+    static __device__ __forceinline__ void update(double (&a)[16]) {
+        if constexpr (C < 16) {
+            a[C] -= a[J] * readlane_d<C>(a[J]);          // a_rC -= l_rJ l_CJ (meaningful for r >= C; zeroed at step C otherwise)
+            update<C + 1>(a);
+        }
+    }
+};
+template <>
+struct DiagStep<16> {
+    static __device__ __forceinline__ void run(double (&)[16], double (&)[16], int, bool&) {}
+};
+
+template <int RR>
+struct InvStep {
+    // entry RR of column r of T = L^-1: t_RR = (delta - sum_{k<RR} l_RR,k t_k) / l_RR,RR, row RR of L broadcast from lane RR
+    static __device__ __forceinline__ void run(const double (&a)[16], const double (&dinv)[16], double (&t)[16], int r) {
+        double acc = (RR == r) ? 1.0 : 0.0;
+        accum<0>(a, t, acc);
+        t[RR] = RR >= r ? acc * dinv[RR] : 0.0;
+        InvStep<RR + 1>::run(a, dinv, t, r);
+    }
+    template <int K>
+    static __device__ __forceinline__ void accum(const double (&a)[16], const double (&t)[16], double& acc) {
+        if constexpr (K < RR) {
+            acc -= readlane_d<RR>(a[K]) * t[K];
+            accum<K + 1>(a, t, acc);
+        }
+    }
+};
+template <>
+struct InvStep<16> {
+    static __device__ __forceinline__ void run(const double (&)[16], const double (&)[16], double (&)[16], int) {}
+};
+
 __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int n = f.n, nx = f.nx, nx1 = f.nx + 1, NP = f.NP, i = threadIdx.x, LDW = n + 1;
+    const int n = f.n, nx = f.nx, nx1 = f.nx + 1, NP = f.NP, i = threadIdx.x;
+    const int nb = (n + 15) / 16, NPD = 16 * nb, LDW = NPD + 1;
+    const int col = i & 15, kq = i >> 4;
     const size_t m = blockIdx.x;
     const double* __restrict__ H = f.H + m * n * n;
     const double* __restrict__ F = f.F + m * n * nx;
     const double* __restrict__ f0 = f.f0 + m * n;
     double* __restrict__ gHs = f.Hs + m * n * n;
     double* __restrict__ gHi = f.Hi + m * n * n;
-    double* sL = reinterpret_cast<double*>(smem);        // lower Cholesky factor of Hs (upper part: Hs itself)
-    double* sT = sL + (size_t)n * LDW;                    // L^-1
-    double* sHi = sL;                                     // Hs^-1 (overwrites L, dead once L^-1 exists)
-    double* sd = sT + (size_t)n * LDW;                    // d
+    double* sL = reinterpret_cast<double*>(smem);        // Hs, then its lower Cholesky factor, finally Hs^-1
+    double* sT = sL + (size_t)NPD * LDW;                  // L^-1 (lower)
+    double* sHi = sL;
+    double* sd = sT + (size_t)NPD * LDW;                  // d
     const bool in = i < n;
     bool bad = false;
     double di = 1.0;
@@ -297,52 +356,92 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
         sd[i] = di;
     }
     wv_sync();
-    // Hs = d H d (symmetrised), row i: coalesced over j by looping rows and letting lanes take columns
-    // (stage H through LDS with coalesced loads only, then symmetrise from LDS)
+    // Hs = d H d (symmetrised): stage H through LDS with coalesced loads, symmetrise from LDS; identity on the padding
 #pragma unroll 8
     for (int r = 0; r < n; ++r) if (in) sT[r * LDW + i] = H[(size_t)r * n + i];
     wv_sync();
-    for (int r = 0; r < n; ++r)
-        if (in) {
+    for (int r = 0; r < NPD; ++r) {
+        if (r < n && in) {
             const double v = 0.5 * (sT[r * LDW + i] + sT[i * LDW + r]) * sd[r] * di;
             sL[r * LDW + i] = v;
             gHs[(size_t)r * n + i] = v;
+        } else if (i < NPD) {
+            sL[r * LDW + i] = (r == i) ? 1.0 : 0.0;
         }
-    wv_sync();
-    // left-looking Cholesky: column j from columns < j
-    for (int j = 0; j < n; ++j) {
-        double v = 0.0;
-        if (in && i >= j) {
-            v = sL[i * LDW + j];
-#pragma unroll 4
-            for (int k = 0; k < j; ++k) v -= sL[i * LDW + k] * sL[j * LDW + k];
-        }
-        const double piv = __shfl(v, j, 64);
-        if (!(piv > 0.0)) { bad = true; }
-        const double rs = (piv > 0.0) ? 1.0 / sqrt(piv) : 1.0;
-        wv_sync();
-        if (in && i >= j) sL[i * LDW + j] = (i == j) ? piv * rs : v * rs;
-        wv_sync();
-    }
-    // T = L^-1, lane c computes column c
-    if (in) {
-        const int c = i;
-        for (int r = c; r < n; ++r) {
-            double sacc = (r == c) ? 1.0 : 0.0;
-#pragma unroll 4
-            for (int k = c; k < r; ++k) sacc -= sL[r * LDW + k] * sT[k * LDW + c];
-            sT[r * LDW + c] = sacc / sL[r * LDW + r];
-        }
-        for (int r = 0; r < c; ++r) sT[r * LDW + c] = 0.0;
     }
     wv_sync();
-    // Hi = T'T, lane i computes row i
-    if (in)
-        for (int j = 0; j < n; ++j) {
-            double sacc = 0.0;
-#pragma unroll 4
-            for (int k = (i > j ? i : j); k < n; ++k) sacc += sT[k * LDW + i] * sT[k * LDW + j];
-            sHi[i * LDW + j] = sacc;
+    for (int e = i; e < NPD * LDW; e += 64) sT[e] = 0.0;
+    wv_sync();
+
+    // ---- blocked Cholesky, L^-1 of the diagonal tiles on the way -----------------------------------------------
+    for (int b = 0; b < nb; ++b) {
+        const int o = 16 * b;
+        double a[16], t[16], dinv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) a[j] = sL[(o + col) * LDW + o + j];
+        DiagStep<0>::run(a, dinv, col, bad);
+        InvStep<0>::run(a, dinv, t, col);
+        wv_sync();
+        if (i < 16) {
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                sL[(o + col) * LDW + o + j] = a[j];             // row col of L_bb (zeros above the diagonal)
+                sT[(o + j) * LDW + o + col] = t[j];             // column col of T_bb
+            }
+        }
+        wv_sync();
+        for (int ib = b + 1; ib < nb; ++ib) {                   // panel: L_ib = S_ib T_bb'
+            d4 acc = {0, 0, 0, 0};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+                acc = mfma_f64(sL[(16 * ib + col) * LDW + o + 4 * s + kq], sT[(o + col) * LDW + o + 4 * s + kq], acc);
+            wv_sync();
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) sL[(16 * ib + kq + 4 * r4) * LDW + o + col] = acc[r4];
+        }
+        wv_sync();
+        for (int ib = b + 1; ib < nb; ++ib)                     // trailing update: S_ij -= L_ib L_jb'
+            for (int jb = b + 1; jb <= ib; ++jb) {
+                d4 acc;
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) acc[r4] = sL[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col];
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = mfma_f64(-sL[(16 * ib + col) * LDW + o + 4 * s + kq], sL[(16 * jb + col) * LDW + o + 4 * s + kq], acc);
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) sL[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = acc[r4];
+            }
+        wv_sync();
+    }
+    // ---- T = L^-1 below the diagonal tiles: T_ib = -T_ii (sum_{b <= j < i} L_ij T_jb) ---------------------------------
+    for (int b = 0; b < nb; ++b)
+        for (int ib = b + 1; ib < nb; ++ib) {
+            d4 w = {0, 0, 0, 0};
+            for (int jb = b; jb < ib; ++jb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    w = mfma_f64(sL[(16 * ib + col) * LDW + 16 * jb + 4 * s + kq], sT[(16 * jb + 4 * s + kq) * LDW + 16 * b + col], w);
+            d4 o4 = {0, 0, 0, 0};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)         // the D registers of w are the B operand of k-step r with k = kq + 4 r
+                o4 = mfma_f64(-sT[(16 * ib + col) * LDW + 16 * ib + kq + 4 * r], w[r], o4);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) sT[(16 * ib + kq + 4 * r4) * LDW + 16 * b + col] = o4[r4];
+            wv_sync();
+        }
+    // ---- Hi = T'T (lower tiles, mirrored), over L ------------------------------------------------------------------------
+    for (int ib = 0; ib < nb; ++ib)
+        for (int jb = 0; jb <= ib; ++jb) {
+            d4 acc = {0, 0, 0, 0};
+            for (int kb = ib; kb < nb; ++kb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+                    acc = mfma_f64(sT[(16 * kb + 4 * s + kq) * LDW + 16 * ib + col], sT[(16 * kb + 4 * s + kq) * LDW + 16 * jb + col], acc);
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                sHi[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = acc[r4];
+                sHi[(16 * jb + col) * LDW + 16 * ib + kq + 4 * r4] = acc[r4];
+            }
         }
     wv_sync();
     for (int r = 0; r < n; ++r) if (in) gHi[(size_t)r * n + i] = sHi[r * LDW + i];
@@ -447,7 +546,8 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
     if (h->n <= 64) {       // one wave per model
-        const size_t wl = ((size_t)2 * h->n * (h->n + 1) + h->n) * sizeof(double);
+        const size_t npd = 16 * (size_t)ceil_div(h->n, 16);
+        const size_t wl = (2 * npd * (npd + 1) + h->n) * sizeof(double);
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
         if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
         hipLaunchKernelGGL(factor_wave_kernel, dim3(h->dims.n_models), dim3(64), wl, st, f);
