@@ -9,6 +9,7 @@
 //   d = diag(H)^-1/2, Hs = d H d,  Hi = Hs^-1,  rho (given or 0.1 sqrt(lmax lmin) from norm bounds),
 //   M = (Hs + rho I)^-1,  Fs1 = [d F | d f0],  Ku1 = -Hi Fs1,  Kb1 = -M Fs1,  lbs = lb/d, ubs = ub/d.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -278,6 +279,14 @@ __device__ __forceinline__ void wv_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
+// 1 / sqrt(x) from v_rsq_f64 and two Newton steps (the division-free form of the pivot scaling)
+__device__ __forceinline__ double frsqrt(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = y * (1.5 - 0.5 * x * y * y);
+    y = y * (1.5 - 0.5 * x * y * y);
+    return y;
+}
+
 template <int SRC>
 __device__ __forceinline__ double readlane_d(double v) {
     const int lo = __builtin_amdgcn_readlane(__double2loint(v), SRC);
@@ -291,7 +300,7 @@ struct DiagStep {
     static __device__ __forceinline__ void run(double (&a)[16], double (&dinv)[16], int r, bool& bad) {
         const double piv = readlane_d<J>(a[J]);
         if (!(piv > 0.0)) bad = true;
-        const double rs = piv > 0.0 ? 1.0 / sqrt(piv) : 1.0;
+        const double rs = piv > 0.0 ? frsqrt(piv) : 1.0;
         dinv[J] = rs;
         a[J] = r < J ? 0.0 : (r == J ? piv * rs : a[J] * rs);
         update<J + 1>(a);
@@ -332,10 +341,13 @@ struct InvStep<16> {
     static __device__ __forceinline__ void run(const double (&)[16], const double (&)[16], double (&)[16], int) {}
 };
 
+// ONE (16 NB) x (16 NB + 1) matrix in LDS holds everything: Hs -> (lower off-diagonal tiles) L_ij, (diagonal tiles) T_bb =
+// L_bb^-1, (upper off-diagonal tile (b, i)) T_ib' ; the tiles of Hi = T'T are accumulated in registers and overwrite it.
+template <int NB>
 __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = f.n, nx = f.nx, nx1 = f.nx + 1, NP = f.NP, i = threadIdx.x;
-    const int nb = (n + 15) / 16, NPD = 16 * nb, LDW = NPD + 1;
+    constexpr int NPD = 16 * NB, LDW = NPD + 1;
     const int col = i & 15, kq = i >> 4;
     const size_t m = blockIdx.x;
     const double* __restrict__ H = f.H + m * n * n;
@@ -343,115 +355,152 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     const double* __restrict__ f0 = f.f0 + m * n;
     double* __restrict__ gHs = f.Hs + m * n * n;
     double* __restrict__ gHi = f.Hi + m * n * n;
-    double* sL = reinterpret_cast<double*>(smem);        // Hs, then its lower Cholesky factor, finally Hs^-1
-    double* sT = sL + (size_t)NPD * LDW;                  // L^-1 (lower)
-    double* sHi = sL;
-    double* sd = sT + (size_t)NPD * LDW;                  // d
+    double* S = reinterpret_cast<double*>(smem);
+    double* sHi = S;
+    double* sd = S + (size_t)NPD * LDW;                   // d (n)
+    double* sF = sd + n;                                  // (n, nx1) scaled [F | f0]; later two probe vectors
     const bool in = i < n;
     bool bad = false;
     double di = 1.0;
+#ifdef FAC_PROF
+    long long tk0 = wall_clock64(), t_ld = 0, t_chol = 0, t_inv = 0, t_hi = 0, t_ku = 0, t_pr = 0;
+#endif
     if (in) {
         const double hii = H[(size_t)i * n + i];
         if (!(hii > 0.0)) bad = true; else di = 1.0 / sqrt(hii);
         sd[i] = di;
     }
-    wv_sync();
-    // Hs = d H d (symmetrised): stage H through LDS with coalesced loads, symmetrise from LDS; identity on the padding
+    // raw H into LDS with coalesced loads (identity on the padding), then symmetrise and scale in place: at step r the
+    // lanes i >= r own the pair (r,i), (i,r)
 #pragma unroll 8
-    for (int r = 0; r < n; ++r) if (in) sT[r * LDW + i] = H[(size_t)r * n + i];
+    for (int r = 0; r < n; ++r) if (in) S[r * LDW + i] = H[(size_t)r * n + i];
+    for (int r = 0; r < NPD; ++r)
+        if (i < NPD && (r >= n || i >= n)) S[r * LDW + i] = (r == i) ? 1.0 : 0.0;
     wv_sync();
-    for (int r = 0; r < NPD; ++r) {
-        if (r < n && in) {
-            const double v = 0.5 * (sT[r * LDW + i] + sT[i * LDW + r]) * sd[r] * di;
-            sL[r * LDW + i] = v;
-            gHs[(size_t)r * n + i] = v;
-        } else if (i < NPD) {
-            sL[r * LDW + i] = (r == i) ? 1.0 : 0.0;
+    for (int r = 0; r < n; ++r) {
+        if (in && i >= r) {
+            const double v = 0.5 * (S[r * LDW + i] + S[i * LDW + r]) * sd[r] * di;
+            S[r * LDW + i] = v;
+            S[i * LDW + r] = v;
         }
     }
     wv_sync();
-    for (int e = i; e < NPD * LDW; e += 64) sT[e] = 0.0;
-    wv_sync();
-
+    for (int r = 0; r < n; ++r) if (in) gHs[(size_t)r * n + i] = S[r * LDW + i];
+#ifdef FAC_PROF
+    { long long tk = wall_clock64(); t_ld += tk - tk0; tk0 = tk; }
+#endif
     // ---- blocked Cholesky, L^-1 of the diagonal tiles on the way -----------------------------------------------
-    for (int b = 0; b < nb; ++b) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
         const int o = 16 * b;
         double a[16], t[16], dinv[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = sL[(o + col) * LDW + o + j];
+        for (int j = 0; j < 16; ++j) a[j] = S[(o + col) * LDW + o + j];
         DiagStep<0>::run(a, dinv, col, bad);
         InvStep<0>::run(a, dinv, t, col);
         wv_sync();
         if (i < 16) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                sL[(o + col) * LDW + o + j] = a[j];             // row col of L_bb (zeros above the diagonal)
-                sT[(o + j) * LDW + o + col] = t[j];             // column col of T_bb
-            }
+            for (int j = 0; j < 16; ++j) S[(o + j) * LDW + o + col] = t[j];     // column col of T_bb replaces the tile
         }
         wv_sync();
-        for (int ib = b + 1; ib < nb; ++ib) {                   // panel: L_ib = S_ib T_bb'
+#pragma unroll
+        for (int ib = b + 1; ib < NB; ++ib) {                   // panel: L_ib = S_ib T_bb'
             d4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                acc = mfma_f64(sL[(16 * ib + col) * LDW + o + 4 * s + kq], sT[(o + col) * LDW + o + 4 * s + kq], acc);
+                acc = mfma_f64(S[(16 * ib + col) * LDW + o + 4 * s + kq], S[(o + col) * LDW + o + 4 * s + kq], acc);
             wv_sync();
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) sL[(16 * ib + kq + 4 * r4) * LDW + o + col] = acc[r4];
+            for (int r4 = 0; r4 < 4; ++r4) S[(16 * ib + kq + 4 * r4) * LDW + o + col] = acc[r4];
         }
         wv_sync();
-        for (int ib = b + 1; ib < nb; ++ib)                     // trailing update: S_ij -= L_ib L_jb'
+#pragma unroll
+        for (int ib = b + 1; ib < NB; ++ib)                     // trailing update: S_ij -= L_ib L_jb'
+#pragma unroll
             for (int jb = b + 1; jb <= ib; ++jb) {
                 d4 acc;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) acc[r4] = sL[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col];
+                for (int r4 = 0; r4 < 4; ++r4) acc[r4] = S[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col];
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    acc = mfma_f64(-sL[(16 * ib + col) * LDW + o + 4 * s + kq], sL[(16 * jb + col) * LDW + o + 4 * s + kq], acc);
+                    acc = mfma_f64(-S[(16 * ib + col) * LDW + o + 4 * s + kq], S[(16 * jb + col) * LDW + o + 4 * s + kq], acc);
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) sL[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = acc[r4];
+                for (int r4 = 0; r4 < 4; ++r4) S[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = acc[r4];
             }
         wv_sync();
     }
-    // ---- T = L^-1 below the diagonal tiles: T_ib = -T_ii (sum_{b <= j < i} L_ij T_jb) ---------------------------------
-    for (int b = 0; b < nb; ++b)
-        for (int ib = b + 1; ib < nb; ++ib) {
+#ifdef FAC_PROF
+    { long long tk = wall_clock64(); t_chol += tk - tk0; tk0 = tk; }
+#endif
+    // ---- T = L^-1 below the diagonal tiles: T_ib = -T_ii (sum_{b <= j < i} L_ij T_jb), stored transposed in tile (b, i) ----
+    // T_jb[k][c]: j == b -> the diagonal tile S[(16b + k)][16b + c];  j > b -> S[(16b + c)][16j + k]
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int ib = b + 1; ib < NB; ++ib) {
             d4 w = {0, 0, 0, 0};
+#pragma unroll
             for (int jb = b; jb < ib; ++jb)
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    w = mfma_f64(sL[(16 * ib + col) * LDW + 16 * jb + 4 * s + kq], sT[(16 * jb + 4 * s + kq) * LDW + 16 * b + col], w);
+                for (int s = 0; s < 4; ++s) {
+                    const int kk = 4 * s + kq;
+                    const double tv = jb == b ? S[(16 * b + kk) * LDW + 16 * b + col] : S[(16 * b + col) * LDW + 16 * jb + kk];
+                    w = mfma_f64(S[(16 * ib + col) * LDW + 16 * jb + kk], tv, w);
+                }
             d4 o4 = {0, 0, 0, 0};
 #pragma unroll
             for (int r = 0; r < 4; ++r)         // the D registers of w are the B operand of k-step r with k = kq + 4 r
-                o4 = mfma_f64(-sT[(16 * ib + col) * LDW + 16 * ib + kq + 4 * r], w[r], o4);
+                o4 = mfma_f64(-S[(16 * ib + col) * LDW + 16 * ib + kq + 4 * r], w[r], o4);
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) sT[(16 * ib + kq + 4 * r4) * LDW + 16 * b + col] = o4[r4];
+            for (int r4 = 0; r4 < 4; ++r4) S[(16 * b + col) * LDW + 16 * ib + kq + 4 * r4] = o4[r4];
             wv_sync();
         }
-    // ---- Hi = T'T (lower tiles, mirrored), over L ------------------------------------------------------------------------
-    for (int ib = 0; ib < nb; ++ib)
-        for (int jb = 0; jb <= ib; ++jb) {
-            d4 acc = {0, 0, 0, 0};
-            for (int kb = ib; kb < nb; ++kb)
+#ifdef FAC_PROF
+    { long long tk = wall_clock64(); t_inv += tk - tk0; tk0 = tk; }
+#endif
+    // ---- Hi = T'T: every lower tile in registers first, then over the matrix (mirrored) ------------------------------------
+    // T_kc[kk][x] for k >= c: k == c -> S[(16c + kk)][16c + x];  k > c -> S[(16c + x)][16k + kk]
+    {
+        d4 hacc[NB * (NB + 1) / 2];
 #pragma unroll
-                for (int s = 0; s < 4; ++s)
-                    acc = mfma_f64(sT[(16 * kb + 4 * s + kq) * LDW + 16 * ib + col], sT[(16 * kb + 4 * s + kq) * LDW + 16 * jb + col], acc);
+        for (int ib = 0; ib < NB; ++ib)
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) {
-                sHi[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = acc[r4];
-                sHi[(16 * jb + col) * LDW + 16 * ib + kq + 4 * r4] = acc[r4];
+            for (int jb = 0; jb <= ib; ++jb) {
+                d4 acc = {0, 0, 0, 0};
+#pragma unroll
+                for (int kb = ib; kb < NB; ++kb)
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) {
+                        const int kk = 4 * s + kq;
+                        const double av = kb == ib ? S[(16 * ib + kk) * LDW + 16 * ib + col] : S[(16 * ib + col) * LDW + 16 * kb + kk];
+                        const double bv = kb == jb ? S[(16 * jb + kk) * LDW + 16 * jb + col] : S[(16 * jb + col) * LDW + 16 * kb + kk];
+                        acc = mfma_f64(av, bv, acc);
+                    }
+                hacc[ib * (ib + 1) / 2 + jb] = acc;
             }
-        }
+        wv_sync();
+#pragma unroll
+        for (int ib = 0; ib < NB; ++ib)
+#pragma unroll
+            for (int jb = 0; jb <= ib; ++jb)
+#pragma unroll
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    const double v = hacc[ib * (ib + 1) / 2 + jb][r4];
+                    sHi[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = v;
+                    sHi[(16 * jb + col) * LDW + 16 * ib + kq + 4 * r4] = v;
+                }
+    }
     wv_sync();
     for (int r = 0; r < n; ++r) if (in) gHi[(size_t)r * n + i] = sHi[r * LDW + i];
+#ifdef FAC_PROF
+    { long long tk = wall_clock64(); t_hi += tk - tk0; tk0 = tk; }
+#endif
     // [Fs | f0s] and [Ku | ku], also transposed (nx+1, NP)
     double* __restrict__ Fs1 = f.Fs1 + m * n * nx1;
     double* __restrict__ Ku1 = f.Ku1 + m * n * nx1;
     double* __restrict__ FsT = f.FsT + m * NP * nx1;
     double* __restrict__ KuT = f.KuT + m * NP * nx1;
-    double* sF = sT;                                      // reuse: (n, nx1)
-    wv_sync();
     if (in)
         for (int c = 0; c < nx1; ++c) {
             const double v = di * (c < nx ? F[(size_t)i * nx + c] : f0[i]);
@@ -471,6 +520,9 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
         }
         if (in) KuT[c * NP + i] = su;
     }
+#ifdef FAC_PROF
+    { long long tk = wall_clock64(); t_ku += tk - tk0; tk0 = tk; }
+#endif
     // accuracy of the explicit inverse, estimated with two probe vectors instead of the full n^2 product (this
     // kernel is instruction bound): max_i |(Hs Hi v - v)_i| for v = ones and v = (+1,-1,...); it only decides
     // whether the solve refines with Hs itself
@@ -482,8 +534,8 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
             for (int j = 0; j < n; ++j) { const double hv = sHi[i * LDW + j]; v1 += hv; v2 += (j & 1) ? -hv : hv; }
         }
         wv_sync();
-        double* p1 = sT;                      // L^-1 is dead: reuse two of its rows
-        double* p2 = sT + LDW;
+        double* p1 = sF;                      // [F | f0] is dead: reuse its space (sized for both uses)
+        double* p2 = sF + n;
         if (in) { p1[i] = v1; p2[i] = v2; }
         wv_sync();
         if (in) {
@@ -512,6 +564,11 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
         f.lbs[m * NP + r] = lo; f.ubs[m * NP + r] = hi;
     }
     if (in) f.d[m * n + i] = di;
+#ifdef FAC_PROF
+    { long long tk = wall_clock64(); t_pr += tk - tk0; }
+    if (i == 0 && (m % 2048) == 0)
+        printf("model %d: load %lld chol %lld inv %lld Hi %lld Fs/Ku %lld probe/bounds %lld (x10 ns)\n", (int)m, t_ld, t_chol, t_inv, t_hi, t_ku, t_pr);
+#endif
 }
 
 }  // namespace
@@ -546,11 +603,13 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st) {
         e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
     if (h->n <= 64) {       // one wave per model
-        const size_t npd = 16 * (size_t)ceil_div(h->n, 16);
-        const size_t wl = (2 * npd * (npd + 1) + h->n) * sizeof(double);
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_wave_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+        const int nb = ceil_div(h->n, 16);
+        const size_t npd = 16 * (size_t)nb;
+        const size_t wl = (npd * (npd + 1) + h->n + std::max<size_t>((size_t)h->n * (h->dims.nx + 1), 2 * (size_t)h->n)) * sizeof(double);
+        auto kern = nb == 1 ? &factor_wave_kernel<1> : nb == 2 ? &factor_wave_kernel<2> : nb == 3 ? &factor_wave_kernel<3> : &factor_wave_kernel<4>;
+        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
         if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
-        hipLaunchKernelGGL(factor_wave_kernel, dim3(h->dims.n_models), dim3(64), wl, st, f);
+        hipLaunchKernelGGL(kern, dim3(h->dims.n_models), dim3(64), wl, st, f);
     } else
     hipLaunchKernelGGL(factor_batch_kernel, dim3(h->dims.n_models), dim3(256), f.use_lds ? lds : 0, st, f);
     e = hipGetLastError();
