@@ -166,3 +166,33 @@ def test_closed_loop_graph_replay_matches_eager_steps():
     u_graph, x_graph = run(4)
     assert np.abs(u_eager - u_graph).max() <= 1e-12
     assert np.abs(x_eager - x_graph).max() <= 1e-12
+
+
+@pytest.mark.parametrize("N,nx,nu", [(4, 3, 2), (16, 4, 4), (19, 5, 3), (30, 3, 3)])
+def test_per_instance_factor_tile_counts(N, nx, nu):
+    """n = 8, 64, 57 (one, four and four padded 16 x 16 tiles of the wave-per-model factor kernel) and n = 90 (the
+    256-thread kernel): scaled Hessian, its explicit inverse and the solve, model by model."""
+    from mpc_amd.planner import Planner
+    rng = np.random.default_rng(100 + N)
+    Bn = 8
+    A0 = 0.9 * np.eye(nx) + 0.1 * np.diag(np.ones(nx - 1), 1)
+    A = A0 + 0.05 * rng.standard_normal((Bn, N, nx, nx))
+    Bm = 0.3 * rng.standard_normal((Bn, N, nx, nu))
+    Q = np.diag(0.5 + rng.random(nx)); R = np.diag(0.05 + 0.1 * rng.random(nu)); P = 2.0 * Q
+    lb = -0.3 - 0.2 * rng.random((Bn, N, nu)); ub = 0.3 + 0.2 * rng.random((Bn, N, nu))
+    x0 = rng.standard_normal((Bn, nx))
+    pl = Planner(nx, nu, N).set_model(A, Bm).set_cost(Q, R, P).set_constraints(lb, ub)
+    U = pl.solve(x0).cpu().numpy().reshape(Bn, -1)
+    assert (pl.info.status.cpu().numpy() == 0).all()
+    obj = pl.info.obj.cpu().numpy()
+    n = N * nu
+    for i in range(Bn):
+        H = pl.get("H", model=i).cpu().numpy().reshape(n, n)
+        d = pl.get("d", model=i).cpu().numpy().reshape(n)
+        Hs = pl.get("Hs", model=i).cpu().numpy().reshape(n, n)
+        Hi = pl.get("Hi", model=i).cpu().numpy().reshape(n, n)
+        assert np.abs(Hs - d[:, None] * H * d[None, :]).max() <= 1e-13 * np.abs(Hs).max()
+        assert np.abs(Hs @ Hi - np.eye(n)).max() <= 1e-9
+        s = _oracle_instance(A[i], Bm[i], Q, R, P, None, None, lb[i], ub[i], x0[i])
+        assert _rel(U[i], s["x"]) <= PRIMAL_RTOL, i
+        assert abs(obj[i] - s["primal objective"]) <= OBJ_RTOL * max(abs(s["primal objective"]), 1e-300), i
