@@ -192,6 +192,11 @@ int  mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double
                       void* stream);
 int  mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, const double* h, double* x, double* z,
                       double* obj, int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream);
+/* the same with the MPC data maps applied on the device: q = F x0 + f0 (F (n,nx), f0 (n)), h = h0 - E x0 (E (m,nx), h0 (m)),
+ * x0 (batch,nx) -- what LaunchPlannerQPFormulation.py:94-121,151-162 evaluate on the host for its one initial state */
+int  mpcqp_rows_solve_mpc(int device_id, int batch, int n, int m, int nx, const double* x0, const double* F,
+                          const double* f0, const double* E, const double* h0, double* x, double* z, double* obj,
+                          int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream);
 
 /* -- scenario model for the closed-loop LTV configuration (BASELINE.json configs[3]; the reference has no counterpart:
  * its scripts keep the model code inline, e.g. CollocationBasedPlanner2D.py:88-347) --------------------------------

@@ -40,6 +40,9 @@ struct GemmParams {
     long lda, ldb, ldc;
     int M, N, K, vec;
     double alpha, beta;
+    // epilogue: C = (alpha acc + bias[j]) (* or /) cscale[j] + beta Cin   (bias, cscale per column; NULL = none; Cin NULL = C)
+    const double *bias, *cscale, *Cin;
+    int cdiv;
 };
 
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams g) {
@@ -106,15 +109,19 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams g) {
                 if (i < g.M && j < g.N) {
                     double* c = g.C + (size_t)i * g.ldc + j;
                     double v = g.alpha * acc[ti][tj][r4];
-                    if (g.beta != 0.0) v += g.beta * *c;
+                    if (g.bias) v += g.bias[j];
+                    if (g.cscale) v = g.cdiv ? v / g.cscale[j] : v * g.cscale[j];
+                    if (g.beta != 0.0) v += g.beta * (g.Cin ? g.Cin[(size_t)i * g.ldc + j] : *c);
                     *c = v;
                 }
             }
 }
 
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int M, int N, int K,
-                   double alpha, double beta, hipStream_t st) {
+                   double alpha, double beta, hipStream_t st, const double* bias = nullptr, const double* cscale = nullptr,
+                   int cdiv = 0, const double* Cin = nullptr) {
     GemmParams g;
+    g.bias = bias; g.cscale = cscale; g.cdiv = cdiv; g.Cin = Cin;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
     g.vec = (lda % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0);
     hipLaunchKernelGGL(gemm_nt_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
@@ -171,7 +178,6 @@ __global__ __launch_bounds__(256) void rows_prep_kernel(PrepParams p) {
             const int r = e - p.n;
             const double v = p.h[(size_t)b * p.m + r] / s.rn[r];
             c[p.l.o_cs + r] = v;
-            c[p.l.o_res + r] = v;        // the residual GEMM turns this into Cs xu - cs
         }
     }
 }
@@ -571,25 +577,38 @@ int mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double*
     return launch_gemm_nt(CH, n, s.Cs, n, Gram, m, m, m, n, 1.0, 0.0, st);          // Gram = CH Cs'
 }
 
-int mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, const double* h, double* x, double* z,
-                     double* obj, int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream) {
-    if (batch < 1 || n < 1 || m < 1 || !q || !h || !x || !status || !shared_ws || !instance_ws) return MPCQP_EINVAL;
+struct MpcMaps { const double *x0, *F, *f0, *E, *h0; int nx; };
+
+static int rows_solve_impl(int device_id, int batch, int n, int m, const double* q, const double* h, const MpcMaps* mp,
+                           double* x, double* z, double* obj, int* status, int* iters, const double* shared_ws,
+                           double* instance_ws, void* stream) {
     if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Layout l = make_layout(n, m);
     const SharedPtrs s = shared_ptrs(shared_ws, n, m);
     const double* CH = shared_ws + l.nd0;
     const double* Gram = CH + (size_t)m * n;
-
-    PrepParams pp;
-    pp.q = q; pp.h = h; pp.ws0 = shared_ws; pp.inst = instance_ws; pp.l = l; pp.n = n; pp.m = m; pp.B = batch;
-    const long total = ((long)n + m) * batch;
-    hipLaunchKernelGGL(rows_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, pp);
-    if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+    int rc;
+    if (mp) {
+        // qs = (x0 F' + f0) d ;  cs = (h0 - x0 E') / rn : two thin GEMMs (K = nx) with the scaling in their epilogue
+        rc = launch_gemm_nt(mp->x0, mp->nx, mp->F, mp->nx, instance_ws + l.o_qs, l.stride, batch, n, mp->nx, 1.0, 0.0, st,
+                            mp->f0, s.d, 0);
+        if (rc != MPCQP_OK) return rc;
+        rc = launch_gemm_nt(mp->x0, mp->nx, mp->E, mp->nx, instance_ws + l.o_cs, l.stride, batch, m, mp->nx, -1.0, 0.0, st,
+                            mp->h0, s.rn, 1);
+        if (rc != MPCQP_OK) return rc;
+    } else {
+        PrepParams pp;
+        pp.q = q; pp.h = h; pp.ws0 = shared_ws; pp.inst = instance_ws; pp.l = l; pp.n = n; pp.m = m; pp.B = batch;
+        const long total = ((long)n + m) * batch;
+        hipLaunchKernelGGL(rows_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, pp);
+        if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+    }
     // xu = -Hi qs ;  res = Cs xu - cs   (both over the whole batch: the shared matrices are read once, not once per QP)
-    int rc = launch_gemm_nt(instance_ws + l.o_qs, l.stride, s.Hi, n, instance_ws + l.o_xu, l.stride, batch, n, n, -1.0, 0.0, st);
+    rc = launch_gemm_nt(instance_ws + l.o_qs, l.stride, s.Hi, n, instance_ws + l.o_xu, l.stride, batch, n, n, -1.0, 0.0, st);
     if (rc != MPCQP_OK) return rc;
-    rc = launch_gemm_nt(instance_ws + l.o_xu, l.stride, s.Cs, n, instance_ws + l.o_res, l.stride, batch, m, n, 1.0, -1.0, st);
+    rc = launch_gemm_nt(instance_ws + l.o_xu, l.stride, s.Cs, n, instance_ws + l.o_res, l.stride, batch, m, n, 1.0, -1.0, st,
+                        nullptr, nullptr, 0, instance_ws + l.o_cs);
     if (rc != MPCQP_OK) return rc;
 
     RowsParams r;
@@ -615,6 +634,21 @@ int mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, co
         hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds2, st, r);
     }
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+int mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, const double* h, double* x, double* z,
+                     double* obj, int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream) {
+    if (batch < 1 || n < 1 || m < 1 || !q || !h || !x || !status || !shared_ws || !instance_ws) return MPCQP_EINVAL;
+    return rows_solve_impl(device_id, batch, n, m, q, h, nullptr, x, z, obj, status, iters, shared_ws, instance_ws, stream);
+}
+
+int mpcqp_rows_solve_mpc(int device_id, int batch, int n, int m, int nx, const double* x0, const double* F, const double* f0,
+                         const double* E, const double* h0, double* x, double* z, double* obj, int* status, int* iters,
+                         const double* shared_ws, double* instance_ws, void* stream) {
+    if (batch < 1 || n < 1 || m < 1 || nx < 1 || !x0 || !F || !f0 || !E || !h0 || !x || !status || !shared_ws || !instance_ws)
+        return MPCQP_EINVAL;
+    const MpcMaps mp{x0, F, f0, E, h0, nx};
+    return rows_solve_impl(device_id, batch, n, m, nullptr, nullptr, &mp, x, z, obj, status, iters, shared_ws, instance_ws, stream);
 }
 
 }  // extern "C"

@@ -292,10 +292,8 @@ class Planner:
         dev = self.device
         lib = self._lib
         B, n, m = x0.shape[0], self.n, gen["G"].shape[0]
-        q = torch.addmm(gen["f0"].unsqueeze(0), x0, gen["F"].t()).contiguous()        # q = F x0 + f0
-        h = (gen["h0"].unsqueeze(0) - x0 @ gen["E"].t()).contiguous()                 # h = h0 - E x0
         x = torch.empty((B, n), dtype=torch.float64, device=dev)
-        z = torch.zeros((B, max(m, 1)), dtype=torch.float64, device=dev)
+        z = torch.empty((B, max(m, 1)), dtype=torch.float64, device=dev)      # both kernels zero the inactive entries
         obj = torch.empty(B, dtype=torch.float64, device=dev)
         st = torch.empty(B, dtype=torch.int32, device=dev)
         iters = torch.empty(B, dtype=torch.int32, device=dev)
@@ -313,11 +311,15 @@ class Planner:
             if gen.get("rows_inst") is None or gen["rows_batch"] < B:
                 gen["rows_inst"] = torch.empty(B * per.value, dtype=torch.float64, device=dev)
                 gen["rows_batch"] = B
-            rc = lib.mpcqp_rows_solve(dev.index or 0, B, n, m, _ptr(q), _ptr(h), _ptr(x), _ptr(z), _ptr(obj), _ptr(st),
-                                      _ptr(iters), _ptr(gen["rows_shared"]), _ptr(gen["rows_inst"]), self._stream())
+            x0 = x0.contiguous()
+            rc = lib.mpcqp_rows_solve_mpc(dev.index or 0, B, n, m, self.nx, _ptr(x0), _ptr(gen["F"]), _ptr(gen["f0"]),
+                                          _ptr(gen["E"]), _ptr(gen["h0"]), _ptr(x), _ptr(z), _ptr(obj), _ptr(st), _ptr(iters),
+                                          _ptr(gen["rows_shared"]), _ptr(gen["rows_inst"]), self._stream())
             if rc != _lib.OK:
-                raise RuntimeError(f"mpcqp_rows_solve failed with code {rc}")
+                raise RuntimeError(f"mpcqp_rows_solve_mpc failed with code {rc}")
             return self._general_info(x, z, obj, st, iters, m, want_multipliers)
+        q = torch.addmm(gen["f0"].unsqueeze(0), x0, gen["F"].t()).contiguous()        # q = F x0 + f0
+        h = (gen["h0"].unsqueeze(0) - x0 @ gen["E"].t()).contiguous()                 # h = h0 - E x0
         ni = C.c_long(0)
         nd = lib.mpcqp_dense_workspace(n, m, 0, C.byref(ni))
         if gen.get("ws") is None or gen["ws_batch"] < B:        # shared set-up: once per model (and per larger batch)
