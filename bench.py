@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0
 ADMM_TRAFFIC_BYTES_65536 = (2 * 49314.40 + 213303.90) * 1024.0   # profiles/r01_v5_pmc.csv
+POLISH_A_TRAFFIC_BYTES_65536 = (2 * 71354.65 + 182863.51) * 1024.0   # first polish_oct_kernel launch; updated from profiles/r01_v7_pmc.csv
 
 
 def cpu_baseline(prob, seconds=15.0):
@@ -186,9 +187,12 @@ def main():
         return e0.elapsed_time(e1) / reps       # ms
 
     reps = max(5, min(args.steps, 20))
-    admm_ms = timed(lambda: pl.solve(x0, stages=1, **opts), reps)
+    admm_on = iters_max > 0
+    admm_ms = timed(lambda: pl.solve(x0, stages=1, **opts), reps) if admm_on else 0.0
     both_ms = timed(lambda: pl.solve(x0, **opts), reps)
     polish_ms = max(both_ms - admm_ms, 0.0)
+    # the first (and longest) active-set launch alone: stages bit 2 stops after it (diagnostic; queued instances stay open)
+    pass_a_ms = max(timed(lambda: pl.solve(x0, stages=7, **opts), reps) - admm_ms, 0.0)
     # p50 / p99 of single-batch solve latency: one event pair per solve
     lat = []
     nlat = max(20, min(args.steps, 100))
@@ -210,11 +214,34 @@ def main():
     n = pl.n
     flops_per_iter = 2 * n * n + 10 * (n + n)
     admm_flops = B * iters_mean * flops_per_iter
-    achieved_tf = admm_flops / (admm_ms * 1e-3) / 1e12
+    achieved_tf = admm_flops / (admm_ms * 1e-3) / 1e12 if admm_on else 0.0
     # compulsory HBM bytes per solve: x0 in, U + info out, plus the (z, w) state the kernels exchange
     hbm_bytes_per_solve = 8 * prob["nx"] + 8 * n + 16 + 4 * 8 * pl.n
     hbm_gbs = B * hbm_bytes_per_solve / (both_ms * 1e-3) / 1e9
 
+    if admm_on:
+        roofline = {"bound": "mfma", "kernel": "admm_shared_box_kernel<8,30>", "achieved": achieved_tf,
+                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
+                    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
+                    # WRITE_SIZE in separate runs; FETCH doubled as the gfx950 guide prescribes), measured at 65,536
+                    # instances and scaled with the batch; not re-measured by this script
+                    "traffic": ADMM_TRAFFIC_BYTES_65536 * B / 65536.0,
+                    "traffic_source": "profiles/r01_v5_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of admm_shared_box_kernel)",
+                    "algorithmic_bytes": B * (8 * prob["nx"] + 3 * 8 * 16 * ((n + 15) // 16)),
+                    "flops_per_launch": admm_flops, "launch_ms": admm_ms}
+    else:
+        # default: no ADMM launch; the dominant kernel is the first active-set pass.  Its algorithmic bytes per instance:
+        # x0 in; U, the (z, w) warm-start state and the info record out.  It is NOT an HBM-streaming kernel: a dependent
+        # chain of fp64 VALU steps per instance -- the fraction is reported as the contract asks
+        pa_bytes = B * (8 * prob["nx"] + 8 * n + 2 * 8 * n + 36)
+        pa_gbs = pa_bytes / (pass_a_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "polish_oct_kernel<8,8,16,512> (first active-set pass)", "achieved": pa_gbs,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pa_gbs / HBM_PEAK_GBS,
+                    "traffic": POLISH_A_TRAFFIC_BYTES_65536 * B / 65536.0,
+                    "traffic_source": "profiles/r01_v7_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of the first polish_oct_kernel launch)",
+                    "algorithmic_bytes": pa_bytes, "launch_ms": pass_a_ms,
+                    "note": "latency/VALU bound by construction: ~8 dependent active-set steps per instance in fp64; "
+                            "VALU busy fraction and instruction counts in DESIGN.md"}
     out = None
     if rank == 0:
         total = world * B * args.steps
@@ -226,23 +253,17 @@ def main():
             "config": {"workload": "configs[2]: quadrotor hover MPC nx=12 nu=4 N=30 (n=120 box-constrained QP), "
                                    f"{B} random x0 per GPU, shared LTI model",
                        "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world} (independent shards)",
-                       "algorithm": "ADMM (shared (Hs+rho I)^-1, fp64 MFMA GEMM form) + dual active-set polish (8/16 lanes per instance, Hs^-1 in LDS)",
+                       "algorithm": ("ADMM (shared (Hs+rho I)^-1, fp64 MFMA GEMM form) + " if admm_on else "") +
+                                    "dual active-set kernels (8/16 lanes per instance, explicit S^-1 in registers, Hs^-1 in LDS)",
                        "admm_iters_mean": iters_mean, "admm_iters_max": iters_max,
                        "polish_steps_mean": psteps_mean, "polish_steps_max": psteps_max,
                        "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": setup_ms,
                        "p50_batch_latency_ms": p50_ms, "p99_batch_latency_ms": p99_ms, "mean_batch_latency_ms": both_ms, "admm_kernel_ms": admm_ms, "polish_kernels_ms": polish_ms,
+                       "first_pass_ms": pass_a_ms,
                        "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if world > 1 else "none",
                        "allgather_ms": allgather_ms,
                        "hbm_GBps_compulsory": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS},
-            "roofline": {"bound": "mfma", "kernel": "admm_shared_box_kernel<8,30>", "achieved": achieved_tf,
-                         "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                         # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc
-                         # FETCH_SIZE and WRITE_SIZE in separate runs; FETCH doubled as the gfx950 guide prescribes),
-                         # measured at 65,536 instances and scaled with the batch; not re-measured by this script
-                         "traffic": ADMM_TRAFFIC_BYTES_65536 * B / 65536.0,
-                         "traffic_source": "profiles/r01_v5_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of admm_shared_box_kernel)",
-                         "algorithmic_bytes": B * (8 * prob["nx"] + 3 * 8 * 16 * ((n + 15) // 16)),
-                         "flops_per_launch": admm_flops, "launch_ms": admm_ms},
+            "roofline": roofline,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -68,7 +68,9 @@ typedef struct mpcqp_factor_opts {
 } mpcqp_factor_opts;
 
 typedef struct mpcqp_solve_opts {
-    int    max_iter;      /* ADMM iteration cap                                   (default 5)   */
+    int    max_iter;      /* ADMM iterations before the active-set stage (default 0: the active-set kernels alone are
+                             fastest when few bounds bind -- 0.57 ms vs 0.78 ms with 5 iterations at BASELINE configs[2];
+                             a few iterations pay off when large active sets must be guessed)                */
     int    min_iter;      /* iterations before the first convergence check        (default 5)   */
     int    check_every;   /* residual / active-set check period                   (default 5)   */
     double eps_abs;       /* OSQP-style absolute tolerance on scaled residuals    (default 1e-6)*/

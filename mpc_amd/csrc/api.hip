@@ -68,7 +68,7 @@ const char* mpcqp_last_error(mpcqp_handle h) { return h ? h->err.c_str() : g_cre
 
 void mpcqp_default_solve_opts(mpcqp_solve_opts* o) {
     if (!o) return;
-    o->max_iter = 5; o->min_iter = 5; o->check_every = 5;
+    o->max_iter = 0; o->min_iter = 5; o->check_every = 5;
     o->eps_abs = 1e-6; o->eps_rel = 1e-6; o->alpha = 1.6;
     o->polish = 1; o->polish_refine = -1; o->polish_max_steps = 0; o->warm_start = 0; o->stages = 3;
 }
@@ -213,7 +213,10 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
         if (!o.polish) { h->err = "solve: one model per instance is solved by the active-set kernel; polish cannot be off"; return MPCQP_EINVAL; }
         o.stages = 2;       // no shared factor, hence no ADMM GEMM: the dual active-set kernel does the whole solve
     }
-    if ((o.stages & 1) && h->dims.n_models == 1) TRY(launch_admm_shared_box(h, x0, batch, o, st));
+    // max_iter = 0 with the polish on: nothing for the ADMM kernel to do -- the active-set kernels start cold (empty set), or
+    // from the kept (z, w) state when warm_start is set
+    const bool skip_admm = o.max_iter == 0 && o.polish && (o.stages & 2);   // polish.hip: no_admm
+    if ((o.stages & 1) && h->dims.n_models == 1 && !skip_admm) TRY(launch_admm_shared_box(h, x0, batch, o, st));
     if (o.stages & 2) TRY(launch_polish_box(h, x0, batch, U, info, o, st));
     h->has_state = true; h->Blast = batch;
     return MPCQP_OK;

@@ -440,7 +440,7 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
             const int j = lane + 64 * q;
             if (j < n) { x[q] = fmin(fmax(zb[j], lo[q]), hi[q]); lam[q] = p.rho * wb[j]; }
         }
-        status = p.cv_ws[inst] ? MPCQP_SOLVED_INACCURATE : MPCQP_MAX_ITER;
+        status = (p.admm_ran && p.cv_ws[inst]) ? MPCQP_SOLVED_INACCURATE : MPCQP_MAX_ITER;
     }
 
     // ---- objective 1/2 x'Hs x + qs'x ---------------------------------------------------------------
@@ -482,9 +482,9 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
     if (lane == 0) {
         if (p.info.status) p.info.status[inst] = status;
         if (p.info.obj) p.info.obj[inst] = obj;
-        if (p.info.iters) p.info.iters[inst] = p.it_ws[inst];
-        if (p.info.prim_res) p.info.prim_res[inst] = p.rp_ws[inst];
-        if (p.info.dual_res) p.info.dual_res[inst] = p.rd_ws[inst];
+        if (p.info.iters) p.info.iters[inst] = p.admm_ran ? p.it_ws[inst] : 0;
+        if (p.info.prim_res) p.info.prim_res[inst] = p.admm_ran ? p.rp_ws[inst] : 0.0;
+        if (p.info.dual_res) p.info.dual_res[inst] = p.admm_ran ? p.rd_ws[inst] : 0.0;
         if (p.info.polish_steps) p.info.polish_steps[inst] = steps;
     }
 }
@@ -545,7 +545,11 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     const bool per_model = h->dims.n_models > 1;
     p.st_nn = per_model ? (long)h->n * h->n : 0; p.st_k = per_model ? (long)h->NP * (h->dims.nx + 1) : 0;
     p.st_np = per_model ? h->NP : 0; p.st_n = per_model ? h->n : 0;
-    p.cold = (per_model && !(o.warm_start && h->has_state)) ? 1 : 0;
+    // cold: no ADMM iterate to start from (one model per instance, or max_iter = 0 without a kept state): the kernels
+    // start from the bounds the unconstrained minimiser violates
+    const bool no_admm = o.max_iter == 0 && o.polish && (o.stages & 1);     // api.hip skipped the ADMM launch
+    p.cold = ((per_model || no_admm) && !(o.warm_start && h->has_state)) ? 1 : 0;
+    p.admm_ran = (!per_model && !no_admm) ? 1 : 0;      // iters / residuals / converged flags are the ADMM kernel's
     p.mflag = per_model ? h->mflag : nullptr;
     p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
@@ -556,7 +560,8 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     // small active sets (the usual case): eight lanes per instance with Hs^-1 in LDS, two passes (polish_quad.hip);
     // what those cannot finish is queued in q2 for the wave-per-instance kernel.  Shapes the fast path does not
     // take (refinement requested, polish off, n > 128) run the wave-per-instance kernel on the whole batch.
-    int rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st);
+    int rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st, (o.stages & 4) != 0);
+    if (rc == 0 && (o.stages & 4)) return MPCQP_OK;         // diagnostics: the first pass alone (bench.py times it)
 #ifdef POLISH_PROF
     if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {
         unsigned long long pr[16]; int cn[2];

@@ -44,7 +44,7 @@ def test_default_opts_and_null_handle_errors():
     lib = _lib.load()
     o = _lib.SolveOpts()
     lib.mpcqp_default_solve_opts(ctypes.byref(o))
-    assert o.max_iter == 5 and o.polish == 1 and o.stages == 3 and abs(o.alpha - 1.6) < 1e-15
+    assert o.max_iter == 0 and o.polish == 1 and o.stages == 3 and abs(o.alpha - 1.6) < 1e-15
     # host-side argument checks that need no device
     assert lib.mpcqp_set_model(None, None, None) == _lib.EINVAL
     assert lib.mpcqp_solve(None, None, 1, None, None, None, None) == _lib.EINVAL

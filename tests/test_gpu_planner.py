@@ -48,13 +48,15 @@ def test_assembly_matches_oracle(cfg, golden_dir):
     assert np.abs(pl.get("Phi").cpu().numpy() - Phi).max() <= 1e-13 * np.abs(Phi).max()
 
 
+@pytest.mark.parametrize("admm", [0, 5])          # active-set kernels alone (the default) / after five ADMM iterations
 @pytest.mark.parametrize("cfg", [1, 2, 3])
-def test_solve_matches_golden(cfg, golden_dir):
+def test_solve_matches_golden(cfg, admm, golden_dir):
     g = np.load(os.path.join(golden_dir, f"mpc_cfg{cfg}.npz"))
     prob = _prob_from_golden(g)
     pl = _planner(prob)
-    U = pl.solve(prob["x0"], want_multipliers=True).cpu().numpy().reshape(len(prob["x0"]), -1)
+    U = pl.solve(prob["x0"], want_multipliers=True, max_iter=admm).cpu().numpy().reshape(len(prob["x0"]), -1)
     info = pl.info
+    assert (info.iters.cpu().numpy() == admm).all()
     assert (info.status.cpu().numpy() == 0).all()
     assert _rel(U, g["U"]).max() <= PRIMAL_RTOL
     obj = info.obj.cpu().numpy()
@@ -65,20 +67,21 @@ def test_solve_matches_golden(cfg, golden_dir):
     assert np.abs(lam - g["lam"]).max() <= 1e-6 * max(1.0, np.abs(g["lam"]).max())
 
 
+@pytest.mark.parametrize("admm", [0, 2, 5])
 @pytest.mark.parametrize("cfg,batch,scale", [(1, 64, 1.0), (2, 96, 8.0), (3, 200, 1.0), (3, 72, 3.0)])
-def test_solve_matches_oracle_seeded(cfg, batch, scale):
+def test_solve_matches_oracle_seeded(cfg, batch, scale, admm):
     from mpc_amd.configs import make_config
     from oracle import mpc_oracle as mo
     from oracle.qp_oracle import solve_box_qp
     prob = make_config(cfg, batch=batch, seed=7)
     prob["x0"] = prob["x0"] * scale
     pl = _planner(prob)
-    U = pl.solve(prob["x0"]).cpu().numpy().reshape(batch, -1)
+    U = pl.solve(prob["x0"], max_iter=admm).cpu().numpy().reshape(batch, -1)
     assert (pl.info.status.cpu().numpy() == 0).all()
     H, F, f0 = mo.condense(prob)
     lb = np.tile(prob["u_min"], prob["N"]); ub = np.tile(prob["u_max"], prob["N"])
     obj = pl.info.obj.cpu().numpy()
-    step = max(1, batch // 24)          # the oracle costs ~50 ms per instance at n = 120
+    step = max(1, batch // (24 if admm == 0 else 8))          # the oracle costs ~50 ms per instance at n = 120
     for i in range(0, batch, step):
         s = solve_box_qp(H, F @ prob["x0"][i] + f0, lb, ub)
         assert s["kkt"]["max"] <= 1e-10
