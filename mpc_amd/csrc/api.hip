@@ -23,7 +23,7 @@ int ensure_batch(mpcqp_handle h, int B) {
     TRY(dev_alloc(h, &h->z, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->w, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->b0ws, (size_t)need * h->NP));
-    TRY(dev_alloc(h, &h->it_ws, (size_t)need * 5 + 16));   // iters | need_big | converged | queue 1 | queue 2 | counters
+    TRY(dev_alloc(h, &h->it_ws, (size_t)need * 6 + 96));   // iters | need_big | converged | queue 1 | queue 2 | counters, buckets | cold-start order
     TRY(dev_alloc(h, &h->rp_ws, (size_t)need));
     TRY(dev_alloc(h, &h->rd_ws, (size_t)need));
     h->Bcap = need;

@@ -49,7 +49,7 @@ struct mpcqp_handle_s {
     int Blast = 0;              // batch of the last solve (for shift / warm start)
     double *z = nullptr, *w = nullptr;     // [Bcap][NP] row-major, scaled variables
     double *b0ws = nullptr;                // [Bcap][NP]: ADMM offsets b0, fragment order per 16 instances
-    int *it_ws = nullptr;                  // [5 Bcap + 16]: iters | need_big | converged | polish queue 1 | queue 2 | counters
+    int *it_ws = nullptr;                  // [6 Bcap + 96]: iters | need_big | converged | polish queue 1 | queue 2 | counters, buckets (96) | cold-start order
     double *rp_ws = nullptr, *rd_ws = nullptr;
     bool assembled = false, factored = false, has_state = false;
     std::string err;

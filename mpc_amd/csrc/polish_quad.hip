@@ -26,6 +26,7 @@
 //
 // Reference counterpart: as polish.hip -- the accuracy of soln['x'] (LaunchPlannerQPFormulation.py:174).
 #include "polish.h"
+#include <cstdlib>
 
 namespace {
 
@@ -750,12 +751,90 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 // on the device and retried by pass B with KMAX = 32 and sixteen lanes per instance on at most
 // `second_cap` queue slots; what is left after that is queued in p2.qout for the wave-per-instance kernel.
 // returns 0 on launch, -1 if the shape does not fit this path, a hipError_t (> 0) otherwise
+// ---- cold start: order the instances by expected work ---------------------------------------------------------------------
+// The lanes of a wave walk their 8 (16) instances in lock-step, so a wave takes as long as its slowest instance.  Without
+// an ADMM iterate the number of bounds the unconstrained minimiser violates predicts the number of active-set steps:
+// instances are bucketed by that count (32 buckets, largest first) and the first pass reads them through the queue.
+constexpr int NBIN = 32;
+
+__global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, int* bins) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int hist[NBIN];
+    const int n = p.n, nx = p.nx, tid = threadIdx.x;
+    double* sKu = reinterpret_cast<double*>(smem);      // (nx+1, n)
+    double* sLb = sKu + (size_t)(nx + 1) * n;
+    double* sUb = sLb + n;
+    for (int idx = tid; idx < (nx + 1) * n; idx += 256) { const int c = idx / n, j = idx - c * n; sKu[idx] = p.KuT[(size_t)c * p.NP + j]; }
+    for (int j = tid; j < n; j += 256) { sLb[j] = p.lbs[j]; sUb[j] = p.ubs[j]; }
+    if (tid < NBIN) hist[tid] = 0;
+    __syncthreads();
+    const int inst = blockIdx.x * 256 + tid;
+    const int xs = nx | 1;                               // odd stride: the per-thread x0 rows do not collide on LDS banks
+    double* sX0 = sUb + n;                               // (256, xs)
+    for (int idx = tid; idx < 256 * nx; idx += 256) {
+        const int l = idx / nx, c = idx - l * nx;
+        const int i2 = blockIdx.x * 256 + l;
+        sX0[l * xs + c] = i2 < p.B ? p.x0[(size_t)i2 * nx + c] : 0.0;
+    }
+    __syncthreads();
+    if (inst < p.B) {
+        const double* x0 = sX0 + tid * xs;
+        int cnt = 0;
+        for (int j = 0; j < n; ++j) {
+            double v = sKu[nx * n + j];
+            for (int c = 0; c < nx; ++c) v += sKu[c * n + j] * x0[c];
+            cnt += (v > sUb[j]) | (v < sLb[j]);
+        }
+        const int key = min(cnt, NBIN - 1);
+        keys[inst] = key;
+        atomicAdd(&hist[key], 1);
+    }
+    __syncthreads();
+    if (tid < NBIN && hist[tid]) atomicAdd(&bins[tid], hist[tid]);
+}
+
+// cursors[k] = number of instances in the buckets above k (largest counts first)
+__global__ void cold_scan_kernel(const int* bins, int* cursors, int* count, int B) {
+    if (threadIdx.x == 0) {
+        int run = 0;
+        for (int k = NBIN - 1; k >= 0; --k) { cursors[k] = run; run += bins[k]; }
+        *count = B;
+    }
+}
+
+__global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, int* cursors, int* order, int B) {
+    __shared__ int hist[NBIN], base[NBIN];
+    const int tid = threadIdx.x, inst = blockIdx.x * 256 + tid;
+    if (tid < NBIN) hist[tid] = 0;
+    __syncthreads();
+    int key = 0, local = 0;
+    if (inst < B) { key = keys[inst]; local = atomicAdd(&hist[key], 1); }
+    __syncthreads();
+    if (tid < NBIN && hist[tid]) base[tid] = atomicAdd(&cursors[tid], hist[tid]);
+    __syncthreads();
+    if (inst < B) order[base[key] + local] = inst;
+}
+
 int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, bool first_pass_only) {
     if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
     hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     PolParams a = p;
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
+    const size_t kl = ((size_t)(p.nx + 1) * p.n + 2 * p.n + 256 * (size_t)(p.nx | 1)) * sizeof(double);
+    if (p.cold && p.B >= 4096 && kl <= 64 * 1024 && !getenv("MPCQP_NO_ORDER")) {
+        // keys in q2 (written again only by the second pass), buckets / cursors / count in the counter block,
+        // the order in the last slot of the int workspace
+        int* keys = q2; int* order = counters + 96;
+        int* bins = counters + 16; int* cursors = bins + NBIN; int* count = counters + 2;
+        e = hipMemsetAsync(bins, 0, NBIN * sizeof(int), st);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 256)), dim3(256), kl, st, p, keys, bins);
+        hipLaunchKernelGGL(cold_scan_kernel, dim3(1), dim3(64), 0, st, bins, cursors, count, p.B);
+        hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, cursors, order, p.B);
+        if ((e = hipGetLastError()) != hipSuccess) return (int)e;
+        a.qin = order; a.qin_count = count;
+    }
     int rc = launch_oct_rp<8, 16, 512>(a, p.B, st);
     if (rc != 0 || first_pass_only) return rc;
     PolParams b = p;
