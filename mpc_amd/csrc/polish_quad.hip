@@ -27,6 +27,7 @@
 // Reference counterpart: as polish.hip -- the accuracy of soln['x'] (LaunchPlannerQPFormulation.py:174).
 #include "polish.h"
 #include <cstdlib>
+#include <algorithm>
 
 namespace {
 
@@ -793,16 +794,21 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
     if (tid < NBIN && hist[tid]) atomicAdd(&bins[tid], hist[tid]);
 }
 
-// cursors[k] = number of instances in the buckets above k (largest counts first)
-__global__ void cold_scan_kernel(const int* bins, int* cursors, int* count, int B) {
+// Buckets >= route go straight to the second pass (its queue q1 / *q1_count): measured on BASELINE configs[2] the final
+// active set is ~1.5x the key (correlation 0.92), so such instances would run the first pass up to its capacity only to
+// start again.  For the others, cursors[k] = number of instances in the first-pass buckets above k (largest first).
+__global__ void cold_scan_kernel(const int* bins, int* cursors, int* count, int* q1_count, int route) {
     if (threadIdx.x == 0) {
         int run = 0;
-        for (int k = NBIN - 1; k >= 0; --k) { cursors[k] = run; run += bins[k]; }
-        *count = B;
+        for (int k = NBIN - 1; k >= route; --k) { cursors[k] = run; run += bins[k]; }
+        *q1_count = run;            // the first pass appends what it cannot finish behind them
+        run = 0;
+        for (int k = route - 1; k >= 0; --k) { cursors[k] = run; run += bins[k]; }
+        *count = run;
     }
 }
 
-__global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, int* cursors, int* order, int B) {
+__global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, int* cursors, int* order, int* q1, int B, int route) {
     __shared__ int hist[NBIN], base[NBIN];
     const int tid = threadIdx.x, inst = blockIdx.x * 256 + tid;
     if (tid < NBIN) hist[tid] = 0;
@@ -812,7 +818,7 @@ __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, int*
     __syncthreads();
     if (tid < NBIN && hist[tid]) base[tid] = atomicAdd(&cursors[tid], hist[tid]);
     __syncthreads();
-    if (inst < B) order[base[key] + local] = inst;
+    if (inst < B) (key >= route ? q1 : order)[base[key] + local] = inst;
 }
 
 int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, bool first_pass_only) {
@@ -830,8 +836,9 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
         e = hipMemsetAsync(bins, 0, NBIN * sizeof(int), st);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 256)), dim3(256), kl, st, p, keys, bins);
-        hipLaunchKernelGGL(cold_scan_kernel, dim3(1), dim3(64), 0, st, bins, cursors, count, p.B);
-        hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, cursors, order, p.B);
+        const int route = std::min(NBIN, 2 * 16 / 3 + 1);          // first-pass capacity 16 rows
+        hipLaunchKernelGGL(cold_scan_kernel, dim3(1), dim3(64), 0, st, bins, cursors, count, counters, route);
+        hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, cursors, order, q1, p.B, route);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
         a.qin = order; a.qin_count = count;
     }
