@@ -82,7 +82,9 @@ typedef struct mpcqp_solve_opts {
     int    polish_max_steps; /* cap on add/drop steps per instance               (default 4n)  */
     int    warm_start;    /* 1: start from the (z, w) kept in the handle          (default 0)   */
     int    stages;        /* bit 0: run the ADMM kernel, bit 1: run polish/finalise (default 3);
-                             1 or 2 alone are for per-kernel timing and reuse the kept (z, w) */
+                             1 or 2 alone are for per-kernel timing and reuse the kept (z, w); bits 2 / 3 (with 3) stop
+                             after the first active-set pass / after the cold-start ordering kernels: timing only, the
+                             batch is left partly solved */
 } mpcqp_solve_opts;
 
 /* all members are device pointers of length batch, each may be NULL */

@@ -24,4 +24,4 @@ struct PolParams {
 };
 
 // fast path; returns MPCQP_ENOTIMPL if the shape does not fit it (the caller then uses the wave kernel)
-int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, bool first_pass_only = false);
+int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, int stop_after = 0);   // diagnostics: 1 = after the first pass, 2 = after the cold-start ordering

@@ -560,8 +560,9 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     // small active sets (the usual case): eight lanes per instance with Hs^-1 in LDS, two passes (polish_quad.hip);
     // what those cannot finish is queued in q2 for the wave-per-instance kernel.  Shapes the fast path does not
     // take (refinement requested, polish off, n > 128) run the wave-per-instance kernel on the whole batch.
-    int rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st, (o.stages & 4) != 0);
-    if (rc == 0 && (o.stages & 4)) return MPCQP_OK;         // diagnostics: the first pass alone (bench.py times it)
+    // diagnostics for bench.py: stages bit 2 stops after the first pass, bit 3 after the cold-start ordering kernels
+    int rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st, (o.stages & 8) ? 2 : ((o.stages & 4) ? 1 : 0));
+    if (rc == 0 && (o.stages & 12)) return MPCQP_OK;
 #ifdef POLISH_PROF
     if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {
         unsigned long long pr[16]; int cn[2];

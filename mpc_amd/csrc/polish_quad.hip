@@ -758,34 +758,48 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 // instances are bucketed by that count (32 buckets, largest first) and the first pass reads them through the queue.
 constexpr int NBIN = 32;
 
+// xu = Ku1 [x0; 1] for 16 instances per wave on fp64 MFMA tiles (A = 16 rows of Ku1, B = [x0; 1] of 16 instances), the
+// violated rows counted straight from the D registers: lane l holds rows (l>>4)+4r of instance l&15
 __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, int* bins) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int hist[NBIN];
-    const int n = p.n, nx = p.nx, tid = threadIdx.x;
-    double* sKu = reinterpret_cast<double*>(smem);      // (nx+1, n)
-    double* sLb = sKu + (size_t)(nx + 1) * n;
-    double* sUb = sLb + n;
-    for (int idx = tid; idx < (nx + 1) * n; idx += 256) { const int c = idx / n, j = idx - c * n; sKu[idx] = p.KuT[(size_t)c * p.NP + j]; }
-    for (int j = tid; j < n; j += 256) { sLb[j] = p.lbs[j]; sUb[j] = p.ubs[j]; }
+    const int n = p.n, nx = p.nx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int KS = (nx + 1 + 3) / 4, KP = 4 * KS, NQ = 16 * ((n + 15) / 16);
+    double* sKu = reinterpret_cast<double*>(smem);      // (KP, NQ): Ku1 transposed, zero padded
+    double* sLb = sKu + (size_t)KP * NQ;                // (NQ) padded rows can never be violated
+    double* sUb = sLb + NQ;
+    double* sX = sUb + NQ;                              // (64, KP): [x0; 1; 0..] of this block's instances
+    for (int idx = tid; idx < KP * NQ; idx += 256) {
+        const int k = idx / NQ, j = idx - k * NQ;
+        sKu[idx] = (k <= nx && j < n) ? p.KuT[(size_t)k * p.NP + j] : 0.0;
+    }
+    for (int j = tid; j < NQ; j += 256) { sLb[j] = j < n ? p.lbs[j] : -1e300; sUb[j] = j < n ? p.ubs[j] : 1e300; }
+    for (int idx = tid; idx < 64 * KP; idx += 256) {
+        const int l = idx / KP, k = idx - l * KP;
+        const int i2 = blockIdx.x * 64 + l;
+        sX[idx] = (i2 < p.B) ? (k < nx ? p.x0[(size_t)i2 * nx + k] : (k == nx ? 1.0 : 0.0)) : 0.0;
+    }
     if (tid < NBIN) hist[tid] = 0;
     __syncthreads();
-    const int inst = blockIdx.x * 256 + tid;
-    const int xs = nx | 1;                               // odd stride: the per-thread x0 rows do not collide on LDS banks
-    double* sX0 = sUb + n;                               // (256, xs)
-    for (int idx = tid; idx < 256 * nx; idx += 256) {
-        const int l = idx / nx, c = idx - l * nx;
-        const int i2 = blockIdx.x * 256 + l;
-        sX0[l * xs + c] = i2 < p.B ? p.x0[(size_t)i2 * nx + c] : 0.0;
-    }
-    __syncthreads();
-    if (inst < p.B) {
-        const double* x0 = sX0 + tid * xs;
-        int cnt = 0;
-        for (int j = 0; j < n; ++j) {
-            double v = sKu[nx * n + j];
-            for (int c = 0; c < nx; ++c) v += sKu[c * n + j] * x0[c];
-            cnt += (v > sUb[j]) | (v < sLb[j]);
+    const int inst = blockIdx.x * 64 + wave * 16 + col;
+    const double* xrow = sX + (size_t)(wave * 16 + col) * KP;
+    int cnt = 0;
+    for (int t = 0; t < NQ / 16; ++t) {
+        d4 acc = {0, 0, 0, 0};
+        for (int s = 0; s < KS; ++s) {
+            const int k = 4 * s + kq;
+            acc = mfma_f64(sKu[k * NQ + 16 * t + col], xrow[k], acc);
         }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = 16 * t + kq + 4 * r;
+            cnt += (acc[r] > sUb[row]) | (acc[r] < sLb[row]);
+        }
+    }
+    cnt += __shfl_xor(cnt, 16);
+    cnt += __shfl_xor(cnt, 32);
+    if (kq == 0 && inst < p.B) {
         const int key = min(cnt, NBIN - 1);
         keys[inst] = key;
         atomicAdd(&hist[key], 1);
@@ -796,54 +810,57 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
 
 // Buckets >= route go straight to the second pass (its queue q1 / *q1_count): measured on BASELINE configs[2] the final
 // active set is ~1.5x the key (correlation 0.92), so such instances would run the first pass up to its capacity only to
-// start again.  For the others, cursors[k] = number of instances in the first-pass buckets above k (largest first).
-__global__ void cold_scan_kernel(const int* bins, int* cursors, int* count, int* q1_count, int route) {
-    if (threadIdx.x == 0) {
-        int run = 0;
-        for (int k = NBIN - 1; k >= route; --k) { cursors[k] = run; run += bins[k]; }
-        *q1_count = run;            // the first pass appends what it cannot finish behind them
-        run = 0;
-        for (int k = route - 1; k >= 0; --k) { cursors[k] = run; run += bins[k]; }
-        *count = run;
-    }
-}
-
-__global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, int* cursors, int* order, int* q1, int B, int route) {
-    __shared__ int hist[NBIN], base[NBIN];
+// start again.  The others are laid out largest bucket first.  Every block derives the bucket offsets from the finished
+// histogram itself; cursors (zeroed by the caller) hand out the places inside a bucket.
+__global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, const int* bins, int* cursors, int* order, int* q1,
+                                                           int* count, int* q1_count, int B, int route) {
+    __shared__ int hist[NBIN], base[NBIN], start[NBIN];
     const int tid = threadIdx.x, inst = blockIdx.x * 256 + tid;
-    if (tid < NBIN) hist[tid] = 0;
+    if (tid < NBIN) {
+        hist[tid] = 0;
+        int run = 0;                // instances of the same class (routed / first pass) in the buckets above mine
+        const int top = tid >= route ? NBIN : route;
+        for (int k = tid + 1; k < top; ++k) run += bins[k];
+        start[tid] = run;
+    }
+    if (blockIdx.x == 0 && tid == 0) {
+        int a = 0, b = 0;
+        for (int k = 0; k < NBIN; ++k) (k >= route ? b : a) += bins[k];
+        *count = a;
+        *q1_count = b;              // the first pass appends what it cannot finish behind the routed ones
+    }
     __syncthreads();
     int key = 0, local = 0;
     if (inst < B) { key = keys[inst]; local = atomicAdd(&hist[key], 1); }
     __syncthreads();
-    if (tid < NBIN && hist[tid]) base[tid] = atomicAdd(&cursors[tid], hist[tid]);
+    if (tid < NBIN && hist[tid]) base[tid] = start[tid] + atomicAdd(&cursors[tid], hist[tid]);
     __syncthreads();
     if (inst < B) (key >= route ? q1 : order)[base[key] + local] = inst;
 }
 
-int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, bool first_pass_only) {
+int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, int stop_after) {
     if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
-    hipError_t e = hipMemsetAsync(counters, 0, 2 * sizeof(int), st);
+    hipError_t e = hipMemsetAsync(counters, 0, 96 * sizeof(int), st);       // queue counters, buckets, cursors
     if (e != hipSuccess) return (int)e;
     PolParams a = p;
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
-    const size_t kl = ((size_t)(p.nx + 1) * p.n + 2 * p.n + 256 * (size_t)(p.nx | 1)) * sizeof(double);
+    const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
+    const size_t kl = ((size_t)kp * nq + 2 * nq + 64 * (size_t)kp) * sizeof(double);
     if (p.cold && p.B >= 4096 && kl <= 64 * 1024 && !getenv("MPCQP_NO_ORDER")) {
         // keys in q2 (written again only by the second pass), buckets / cursors / count in the counter block,
         // the order in the last slot of the int workspace
         int* keys = q2; int* order = counters + 96;
         int* bins = counters + 16; int* cursors = bins + NBIN; int* count = counters + 2;
-        e = hipMemsetAsync(bins, 0, NBIN * sizeof(int), st);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 256)), dim3(256), kl, st, p, keys, bins);
+        hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins);
         const int route = std::min(NBIN, 2 * 16 / 3 + 1);          // first-pass capacity 16 rows
-        hipLaunchKernelGGL(cold_scan_kernel, dim3(1), dim3(64), 0, st, bins, cursors, count, counters, route);
-        hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, cursors, order, q1, p.B, route);
+        hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, bins, cursors, order, q1, count,
+                           counters, p.B, route);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
         a.qin = order; a.qin_count = count;
     }
+    if (stop_after == 2) return 0;
     int rc = launch_oct_rp<8, 16, 512>(a, p.B, st);
-    if (rc != 0 || first_pass_only) return rc;
+    if (rc != 0 || stop_after == 1) return rc;
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
     return launch_oct_rp<16, 32, 256>(b, p.B, st);
