@@ -239,6 +239,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
                 // cold (no ADMM iterate): start from the empty set.  Guessing the bounds the unconstrained minimiser
                 // violates was measured and is slower (0.67 vs 0.58 ms per batch): the guess overshoots, the warm phase
                 // has to factor and prune it and more instances outgrow the first pass
+                // (the same guess for the heavy instances of the second pass only: also slower, 138 vs 146 M solves/s)
                 if (p.cold) continue;
                 if (zz[j] >= hi - tz && ww[j] > tw) mU |= 1u << j;
                 else if (zz[j] <= lo + tz && ww[j] < -tw) mL |= 1u << j;
@@ -852,7 +853,8 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
         int* keys = q2; int* order = counters + 96;
         int* bins = counters + 16; int* cursors = bins + NBIN; int* count = counters + 2;
         hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins);
-        const int route = std::min(NBIN, 2 * 16 / 3 + 1);          // first-pass capacity 16 rows
+        int route = std::min(NBIN, 2 * 16 / 3);                    // first-pass capacity 16 rows; swept 8..14: 10 is best
+        if (const char* ev = getenv("MPCQP_ROUTE")) route = std::max(1, std::min(NBIN, atoi(ev)));   // tuning experiments
         hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, bins, cursors, order, q1, count,
                            counters, p.B, route);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
