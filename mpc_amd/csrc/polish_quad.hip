@@ -343,8 +343,8 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     };
 
     PROF_MARK(1);
-    // ---- warm phase ---------------------------------------------------------------------------------
-    {
+    // ---- warm phase (skipped by a wave none of whose instances has a guess: every cold start) -----------
+    if (__any(valid && (mU | mL) != 0u)) {
         // ordered list of the guessed set: lane g's rows after those of lanes < g
         const unsigned m = mU | mL;
         int* cntp = reinterpret_cast<int*>(myR);
