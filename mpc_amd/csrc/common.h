@@ -35,6 +35,7 @@ struct mpcqp_handle_s {
     // shared-model solver data (model 0)
     double *d = nullptr, *Hs = nullptr, *M = nullptr, *Hi = nullptr, *W1 = nullptr, *W2 = nullptr;
     double *Fs1 = nullptr;      // (n, nx+1): [Fs | f0s]   qs = Fs1 [x0;1]
+    double *Cq = nullptr;       // (nx+1, nx+1): Fs1' Ku1 (shared model): qs'x_unc = [x0;1]' Cq [x0;1]
     double *Ku1 = nullptr;      // (n, nx+1): [Ku | ku]    x_unc = Ku1 [x0;1]
     double *FsT = nullptr, *KuT = nullptr;   // the same two maps transposed, (nx+1, NP): coalesced per-row reads
     double *Mfrag = nullptr, *Kbfrag = nullptr, *Kufrag = nullptr;

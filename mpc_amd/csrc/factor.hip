@@ -15,7 +15,7 @@ namespace {
 
 struct FacParams {
     const double *H, *F, *f0, *umin, *umax;
-    double *d, *Hs, *M, *Hi, *W1, *W2, *Fs1, *Ku1, *FsT, *KuT, *Mfrag, *Kbfrag, *Kufrag, *lbs, *ubs, *rho_dev;
+    double *d, *Hs, *M, *Hi, *W1, *W2, *Fs1, *Ku1, *Cq, *FsT, *KuT, *Mfrag, *Kbfrag, *Kufrag, *lbs, *ubs, *rho_dev;
     int* flag;
     int n, nx, nu, NT, S, SX, per_stage;
     double rho_in;
@@ -139,6 +139,13 @@ __global__ __launch_bounds__(256) void factor_kernel(FacParams f) {
         for (int sft = 128; sft > 0; sft >>= 1) { if (tid < sft) red[tid] = fmax(red[tid], red[tid + sft]); __syncthreads(); }
         if (tid == 0) f.rho_dev[3] = red[0];
         __syncthreads();
+    }
+    // Cq = Fs1' Ku1: the active-set kernels get qs'x_unc as a quadratic form in [x0; 1] instead of forming qs
+    for (int idx = tid; idx < nx1 * nx1; idx += 256) {
+        const int a = idx / nx1, b = idx % nx1;
+        double sacc = 0.0;
+        for (int i = 0; i < n; ++i) sacc += f.Fs1[(size_t)i * nx1 + a] * f.Ku1[(size_t)i * nx1 + b];
+        f.Cq[idx] = sacc;
     }
     const int NP = 16 * f.NT;
     for (int idx = tid; idx < NP * nx1; idx += 256) {
@@ -577,7 +584,7 @@ int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
     FacParams f;
     f.H = h->H; f.F = h->F; f.f0 = h->f0; f.umin = h->umin; f.umax = h->umax;
     f.d = h->d; f.Hs = h->Hs; f.M = h->M; f.Hi = h->Hi; f.W1 = h->W1; f.W2 = h->W2;
-    f.Fs1 = h->Fs1; f.Ku1 = h->Ku1; f.FsT = h->FsT; f.KuT = h->KuT; f.Mfrag = h->Mfrag; f.Kbfrag = h->Kbfrag; f.Kufrag = h->Kufrag;
+    f.Fs1 = h->Fs1; f.Ku1 = h->Ku1; f.Cq = h->Cq; f.FsT = h->FsT; f.KuT = h->KuT; f.Mfrag = h->Mfrag; f.Kbfrag = h->Kbfrag; f.Kufrag = h->Kufrag;
     f.lbs = h->lbs; f.ubs = h->ubs; f.rho_dev = h->rho_dev; f.flag = h->flag_dev;
     f.n = h->n; f.nx = h->dims.nx; f.nu = h->dims.nu; f.NT = h->NT; f.S = h->S; f.SX = h->SX;
     f.per_stage = h->per_stage; f.rho_in = rho;

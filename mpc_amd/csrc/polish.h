@@ -17,7 +17,7 @@ struct PolParams {
     double rho;
     long st_nn, st_k, st_np, st_n;  // one model per instance: element strides of (Hs,Hi), (FsT,KuT), (lbs,ubs), d; 0 = shared
     const int* mflag;              // per-model factorisation failure flags (nullptr: shared model)
-    int cold; int admm_ran;                      // 1: no (z, w) to start from -- begin with the empty active set
+    int cold; int admm_ran; const double* Cq;                      // 1: no (z, w) to start from -- begin with the empty active set
     const int *qin, *qin_count;    // instance queue to take the work from (nullptr: instances 0..B-1)
     int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)
     unsigned long long* prof;      // debugging only (POLISH_PROF builds): per-phase cycle sums, else nullptr

@@ -550,6 +550,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     const bool no_admm = o.max_iter == 0 && o.polish && (o.stages & 1);     // api.hip skipped the ADMM launch
     p.cold = ((per_model || no_admm) && !(o.warm_start && h->has_state)) ? 1 : 0;
     p.admm_ran = (!per_model && !no_admm) ? 1 : 0;      // iters / residuals / converged flags are the ADMM kernel's
+    p.Cq = per_model ? nullptr : h->Cq;
     p.mflag = per_model ? h->mflag : nullptr;
     p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }

@@ -191,7 +191,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     for (int idx = tid; idx < (nx + 1) * NQ; idx += THREADS) {
         const int c = idx / NQ, j = idx - c * NQ;
         sKu[idx] = (j < n) ? p.KuT[(size_t)c * p.NP + j] : 0.0;
-        sFs[idx] = (j < n) ? p.FsT[(size_t)c * p.NP + j] : 0.0;
+        if (!p.Cq) sFs[idx] = (j < n) ? p.FsT[(size_t)c * p.NP + j] : 0.0;
     }
     for (int idx = tid; idx < IPW * nx; idx += THREADS) {
         const int l2 = idx / nx, c = idx - l2 * nx;
@@ -213,16 +213,26 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 #pragma unroll
             for (int j = 0; j < RPL; ++j) x[j] += sKu[c * NQ + ROWJ(j)] * xc;
         }
-        double q[RPL];
+        if (p.Cq) {         // c0 = [x0;1]' Cq [x0;1], rows a = g, g+G, .. of the form in lane g
+            const int nx1 = nx + 1;
+            for (int a = g; a < nx1; a += G) {
+                const double* cr = p.Cq + (size_t)a * nx1;
+                double sa = cr[nx];
+                for (int b = 0; b < nx; ++b) sa += cr[b] * sX0[li * nx + b];
+                c0 += sa * (a < nx ? sX0[li * nx + a] : 1.0);
+            }
+        } else {
+            double q[RPL];
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) q[j] = sFs[nx * NQ + ROWJ(j)];
-        for (int c = 0; c < nx; ++c) {
-            const double xc = sX0[li * nx + c];
+            for (int j = 0; j < RPL; ++j) q[j] = sFs[nx * NQ + ROWJ(j)];
+            for (int c = 0; c < nx; ++c) {
+                const double xc = sX0[li * nx + c];
 #pragma unroll
-            for (int j = 0; j < RPL; ++j) q[j] += sFs[c * NQ + ROWJ(j)] * xc;
+                for (int j = 0; j < RPL; ++j) q[j] += sFs[c * NQ + ROWJ(j)] * xc;
+            }
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) c0 += q[j] * x[j];
         }
-#pragma unroll
-        for (int j = 0; j < RPL; ++j) c0 += q[j] * x[j];
         c0 = grp_sum<G>(c0);
     }
 
