@@ -51,7 +51,8 @@ __device__ __forceinline__ double grp_sum(double v) {
     v += dpp_d<DPP_XOR1>(v);
     v += dpp_d<DPP_XOR2>(v);
     v += dpp_d<DPP_HMIRROR>(v);
-    if (G == 16) v += dpp_d<DPP_ROR8>(v);
+    if (G >= 16) v += dpp_d<DPP_ROR8>(v);
+    if (G == 32) v += __shfl_xor(v, 16);        // across the two DPP rows of the group
     return v;
 }
 template <int CTRL>
@@ -63,14 +64,19 @@ __device__ __forceinline__ void min_step(double& t, int& j) {
 template <int G>
 __device__ __forceinline__ void grp_min(double& t, int& j) {
     min_step<DPP_XOR1>(t, j); min_step<DPP_XOR2>(t, j); min_step<DPP_HMIRROR>(t, j);
-    if (G == 16) min_step<DPP_ROR8>(t, j);
+    if (G >= 16) min_step<DPP_ROR8>(t, j);
+    if (G == 32) {
+        const double ot = __shfl_xor(t, 16); const int oj = __shfl_xor(j, 16);
+        if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
+    }
 }
 template <int CTRL>
 __device__ __forceinline__ void imin_step(int& j) { const int oj = dpp_i<CTRL>(j); j = oj < j ? oj : j; }
 template <int G>
 __device__ __forceinline__ int grp_imin(int j) {
     imin_step<DPP_XOR1>(j); imin_step<DPP_XOR2>(j); imin_step<DPP_HMIRROR>(j);
-    if (G == 16) imin_step<DPP_ROR8>(j);
+    if (G >= 16) imin_step<DPP_ROR8>(j);
+    if (G == 32) { const int oj = __shfl_xor(j, 16); j = oj < j ? oj : j; }
     return j;
 }
 template <int CTRL>
@@ -81,7 +87,11 @@ __device__ __forceinline__ void max_step(double& v, int& code) {
 template <int G>
 __device__ __forceinline__ void grp_max(double& v, int& code) {
     max_step<DPP_XOR1>(v, code); max_step<DPP_XOR2>(v, code); max_step<DPP_HMIRROR>(v, code);
-    if (G == 16) max_step<DPP_ROR8>(v, code);
+    if (G >= 16) max_step<DPP_ROR8>(v, code);
+    if (G == 32) {
+        const double ov = __shfl_xor(v, 16); const int oc = __shfl_xor(code, 16);
+        if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
+    }
 }
 
 constexpr int BIGI = 1 << 20;
@@ -875,5 +885,5 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (rc != 0 || stop_after == 1) return rc;
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
-    return launch_oct_rp<16, 32, 256>(b, p.B, st);
+    return launch_oct_rp<32, 32, 512>(b, p.B, st);
 }
