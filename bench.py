@@ -193,7 +193,7 @@ def main():
     polish_ms = max(both_ms - admm_ms, 0.0)
     # the first (and longest) active-set launch alone: stages bit 2 stops after it (diagnostic; queued instances stay open)
     # (bit 3: after the cold-start ordering kernels, which run before it)
-    order_ms = timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms
+    order_ms = max(timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms, 0.0)
     pass_a_ms = max(timed(lambda: pl.solve(x0, stages=7, **opts), reps) - admm_ms - order_ms, 0.0)
     # p50 / p99 of single-batch solve latency: one event pair per solve
     lat = []
