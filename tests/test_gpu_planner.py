@@ -236,8 +236,8 @@ def test_predict_matches_prediction_matrices(cfg):
     assert np.abs(X - Xo).max() <= 1e-12 * max(1.0, np.abs(Xo).max())
 
 
-@pytest.mark.parametrize("cfg,batch", [(2, 4096), (3, 65536)])
-def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch):
+@pytest.mark.parametrize("cfg,batch,x0_scale", [(2, 4096, 1.0), (3, 65536, 1.0), (3, 8192, 2.5)])
+def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale):
     """BASELINE.json's full sizes (4,096 cart-poles; 65,536 quadrotors): the oracle cannot visit every instance in
     seconds, so parity at this size is the solver-independent optimality certificate, evaluated for ALL instances
     (on the device, from H and F themselves): feasibility, stationarity on the free rows, multiplier signs on the
@@ -245,8 +245,10 @@ def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch):
     import torch
     from mpc_amd.configs import make_config
     prob = make_config(cfg, batch=batch, seed=1)
+    # scale 2.5: far-out initial states -- large active sets, so the cold-start routing sends many instances straight to
+    # the second pass and some on to the wave-per-instance kernel
     pl = _planner(prob)
-    x0 = torch.as_tensor(prob["x0"], device="cuda:0")
+    x0 = torch.as_tensor(prob["x0"] * x0_scale, device="cuda:0")
     U = pl.solve(x0).reshape(batch, -1)
     assert bool((pl.info.status == 0).all())
     H, F, f0 = pl.get("H"), pl.get("F"), pl.get("f0")
@@ -265,6 +267,9 @@ def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch):
     assert bool(((pl.info.obj - obj).abs() <= 1e-8 * obj.abs().clamp_min(1e-9)).all())
     # the bounds do bind: on average more than once per instance for the quadrotors, now and then for the cart-poles
     assert int((~free).sum()) > (batch if cfg == 3 else 0)
+    if x0_scale > 1.0:
+        nact = (~free).sum(1)
+        assert int((nact > 16).sum()) > batch // 20 and int(nact.max()) > 32     # every pass of the chain is exercised
 
 
 @pytest.mark.parametrize("nx,nu,N", [(3, 1, 25), (5, 3, 11), (33, 2, 12), (2, 1, 128)])
