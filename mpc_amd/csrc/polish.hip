@@ -427,6 +427,10 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
         }
     }
 
+    if (overflow && p.qout) {               // queue mode: hand the instance to the next, larger pass
+        if (lane == 0) p.qout[atomicAdd(p.qout_count, 1)] = inst;
+        return;
+    }
     if (overflow && p.pass == 0) {          // redo in the big pass
         if (lane == 0) p.need_big[inst] = 1;
         return;
@@ -577,8 +581,14 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     }
 #endif
     if (rc == 0) {
-        p.pass = 1; p.qin = q2; p.qin_count = counters + 1;
-        rc = launch_pol<128, 1>(p, st, 512);
+        // what the two fast passes could not finish: up to 64 active rows with four waves per workgroup (eight waves per
+        // CU), the rest (queue 1 is free again) with one wave per workgroup and room for every row
+        p.pass = 1; p.qin = q2; p.qin_count = counters + 1; p.qout = q1; p.qout_count = counters + 3;
+        rc = launch_pol<64, 4>(p, st, 512);
+        if (rc == 0) {
+            p.qin = q1; p.qin_count = counters + 3; p.qout = nullptr; p.qout_count = nullptr;
+            rc = launch_pol<128, 1>(p, st, 512);
+        }
     } else if (rc < 0) {
         rc = launch_pol<32, 4>(p, st);
         if (rc == 0 && o.polish) { p.pass = 1; rc = launch_pol<128, 1>(p, st); }
