@@ -32,7 +32,7 @@ sys.path.insert(0, ROOT)
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (datasheet)
 HBM_PEAK_GBS = 8000.0
 ADMM_TRAFFIC_BYTES_65536 = (2 * 49314.40 + 213303.90) * 1024.0   # profiles/r01_v5_pmc.csv
-POLISH_A_TRAFFIC_BYTES_65536 = (2 * 7216.07 + 185924.80) * 1024.0   # first polish_oct_kernel launch, profiles/r01_v7_pmc.csv
+POLISH_A_TRAFFIC_BYTES_65536 = (2 * 7200.65 + 185924.27) * 1024.0   # first polish_oct_kernel launch, profiles/r01_v7_pmc.csv
 
 
 def cpu_baseline(prob, seconds=15.0):
