@@ -165,6 +165,22 @@ int  mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const doub
                        double* x, double* z, double* y, double* obj, int* status, int* iters,
                        double* workspace, int* int_workspace, void* stream);
 
+/* mpcqp_solve_dense for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers of this
+ * boundary that may not call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
+ * allocation) and therefore cannot bring the workspace mpcqp_solve_dense asks for.  The workspace is a static device
+ * array inside the library (MPCQP_DENSE_STATIC_DOUBLES doubles + MPCQP_DENSE_STATIC_INTS ints, about 16.3 MB, held by
+ * every GPU the library runs on until the process ends); the call allocates nothing and frees nothing.
+ * Limit: batch * mpcqp_dense_workspace(n,m,p,&ni) <= MPCQP_DENSE_STATIC_DOUBLES and batch * ni <= MPCQP_DENSE_STATIC_INTS,
+ * otherwise MPCQP_ENOTIMPL and nothing is launched (e.g. 3 QPs of CollocationBasedPlanner2D.py:359's size n=280, m=236,
+ * p=188, or 860 of SE3Planner.py:183's n=18, m=12).  All calls on one GPU share that GPU's array: calls that overlap on
+ * one GPU (two streams, two threads) race; calls on one stream are ordered and safe.  Same arguments, outputs and
+ * status codes as mpcqp_solve_dense otherwise. */
+#define MPCQP_DENSE_STATIC_DOUBLES (2L << 20)
+#define MPCQP_DENSE_STATIC_INTS    (64L << 10)
+int  mpcqp_solve_dense_static(int device_id, int batch, int n, int m, int p, const double* P, const double* q,
+                              const double* G, const double* h, const double* A, const double* b,
+                              double* x, double* z, double* y, double* obj, int* status, int* iters, void* stream);
+
 /* the same with explicit strides (doubles between consecutive QPs; 0 = one array shared by the whole batch): the MPC
  * case with state / polytopic rows has ONE Hessian and ONE constraint matrix [I; Gamma rows; C Gamma rows]
  * (LaunchPlannerQPFormulation.py:94-121, Launch3DPlanner.py:115-160) and per-instance q = F x0 + f0, h = h0 - E x0 */

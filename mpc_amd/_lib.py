@@ -60,6 +60,7 @@ SYMBOLS = [
     ("mpcqp_dense_shared_setup", C.c_int, [C.c_int] * 4 + [C.c_void_p] * 6),
     ("mpcqp_dense_shared_solve", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 12),
     ("mpcqp_solve_dense", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 14 + [C.c_void_p]),
+    ("mpcqp_solve_dense_static", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 12 + [C.c_void_p]),
     ("mpcqp_rows_workspace", C.c_long, [C.c_int, C.c_int, C.POINTER(C.c_long)]),
     ("mpcqp_rows_setup", C.c_int, [C.c_int] * 3 + [C.c_void_p] * 5),
     ("mpcqp_rows_solve", C.c_int, [C.c_int] * 4 + [C.c_void_p] * 10),

@@ -18,6 +18,8 @@
 // what the 1e-6 / 1e-8 parity bar needs; an interior-point or ADMM iteration would not on these
 // badly scaled problems (LaunchPlannerQPFormulation.py: eig(P) = 1e-8 .. 3e-5).
 #include "common.h"
+#include <algorithm>
+#include <mutex>
 
 namespace {
 
@@ -602,6 +604,58 @@ int mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const doubl
                       double* workspace, int* int_workspace, void* stream) {
     return mpcqp_solve_dense_strided(device_id, batch, n, m, p, P, (long)n * n, q, n, G, (long)m * n, h, m, A, (long)p * n,
                                      b, p, x, z, y, obj, status, iters, workspace, int_workspace, stream);
+}
+
+}  // extern "C"
+
+// ---- the same solve for callers that cannot allocate (HIP graph capture, serving loops, harnesses that forbid hipMalloc):
+// the workspace is a file-scope device array instead of an argument.  Every GPU holds its own copy of the array at its own
+// address; the name `scratch` is only a host-side stand-in for it, so host code goes through the per-device pointer that
+// hipGetSymbolAddress returns and never through the name.
+namespace {
+
+constexpr long STATIC_WS_DOUBLES = MPCQP_DENSE_STATIC_DOUBLES;
+constexpr long STATIC_WS_INTS = MPCQP_DENSE_STATIC_INTS;
+constexpr int STATIC_MAX_DEVICES = 64;
+
+static __device__ __align__(256) double scratch[STATIC_WS_DOUBLES + STATIC_WS_INTS / 2];
+
+double* g_scratch_ptr[STATIC_MAX_DEVICES];      // device address of `scratch` on each GPU, resolved once per device
+std::mutex g_scratch_mutex;
+
+// device_id must be the current device
+int static_scratch(int device_id, double** out) {
+    if (device_id < 0 || device_id >= STATIC_MAX_DEVICES) return MPCQP_EINVAL;
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (!g_scratch_ptr[device_id]) {
+        void* ptr = nullptr;
+        if (hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)) != hipSuccess || !ptr) return MPCQP_EHIP;
+        g_scratch_ptr[device_id] = static_cast<double*>(ptr);
+    }
+    *out = g_scratch_ptr[device_id];
+    return MPCQP_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int mpcqp_solve_dense_static(int device_id, int batch, int n, int m, int p, const double* P, const double* q,
+                             const double* G, const double* h, const double* A, const double* b,
+                             double* x, double* z, double* y, double* obj, int* status, int* iters, void* stream) {
+    if (batch < 1 || n < 1 || m < 0 || p < 0) return MPCQP_EINVAL;
+    long ic = 0;
+    const long per = mpcqp_dense_workspace(n, m, p, &ic);
+    // sizes beyond the static array are an error, never a silent allocation
+    if (per > STATIC_WS_DOUBLES / batch || ic > STATIC_WS_INTS / batch) return MPCQP_ENOTIMPL;
+    if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
+    double* ws = nullptr;
+    const int rc = static_scratch(device_id, &ws);
+    if (rc != MPCQP_OK) return rc;
+    int* iws = reinterpret_cast<int*>(ws + STATIC_WS_DOUBLES);
+    // the kernel writes every workspace entry before it reads it (callers of mpcqp_solve_dense pass uninitialised
+    // memory), so the contents the previous call left behind need no clearing
+    return mpcqp_solve_dense(device_id, batch, n, m, p, P, q, G, h, A, b, x, z, y, obj, status, iters, ws, iws, stream);
 }
 
 }  // extern "C"
