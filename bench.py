@@ -1,182 +1,217 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MPC QP hot path on MI355X.
+"""bench.py -- benchmarks of the MPC QP hot path on MI355X.
 
-Metric (BASELINE.json): QP solves/sec at batch 65,536, nx=12 nu=4 N=30 (quadrotor hover MPC,
-config 3), fp64, synthetic x0 (numpy default_rng(seed)), random-free model.  One "step" = one
-pass of the hot path over one batch: mpcqp_solve (ADMM kernel + polish kernel) with x0 already
-resident in HBM; the model set-up (assemble + factor) is outside the timed region because the
-model is shared and fixed (LTI) -- it is reported as `setup_ms`.
+Default = the headline metric (BASELINE.json): QP solves/sec at batch 65,536, nx=12 nu=4 N=30 (quadrotor hover MPC,
+configs[2] = "config 3" in SURVEY.md's 1-based numbering), fp64, synthetic x0 (numpy default_rng(0)).  One "step" = one
+pass of the hot path over the batch: mpcqp_solve (cold-start ordering kernels + dual active-set kernels) with x0 already
+resident in HBM; the model set-up (assemble + factor) is outside the timed region because the model is shared and fixed
+(LTI) -- it is reported as `setup_ms`.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5] [--scaling strong|weak]
 
-N > 1 is launched by the driver as torch.distributed.run with one rank per GPU; every rank solves
-its own 65,536-instance shard (weak scaling, no data-path collective), the step ends with the
-all-reduce of the "all solved" flag the north star names; the all-gather of the solutions is timed
-separately (config.allgather_ms) because its volume grows with N and a caller only needs it when
-the host wants every trajectory.
+--gpus N > 1: if the ranks do not exist yet (WORLD_SIZE unset) this process starts them itself -- N fresh children under
+torch.distributed.run, BEFORE it touches the GPU -- relays rank 0's JSON line and exits with their code.  Under the
+driver's own torch.distributed.run the ranks already exist and it just runs as one of them.
+Scaling (BASELINE.json configs[2]): "strong" (default) = the 65,536 x0 are SPLIT over the ranks, rank r
+solves rows shard_range(65536, r, N); "weak" = 65,536 per GPU.  No data-path collective: instances are independent.  Every
+step ends with the all-reduce(MIN) of the all-solved flag; the all-gather of the solutions is timed separately
+(config.allgather_ms).
+
+Other workloads (same JSON schema, `config.workload` names them): --config 2 cart-pole 4,096 instances; --config 4
+kinematic-bicycle LTV closed loop, 8,192 rollouts, one step = one closed-loop step of every rollout (default 1,000 steps);
+--config 5 long-horizon N=100 with state box + polytopic rows, 256 instances.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (datasheet)
+FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-ADMM_TRAFFIC_BYTES_65536 = (2 * 49314.40 + 213303.90) * 1024.0   # profiles/r01_v5_pmc.csv
-POLISH_A_TRAFFIC_BYTES_65536 = (2 * 7200.65 + 185924.27) * 1024.0   # first polish_oct_kernel launch, profiles/r01_v7_pmc.csv
+# HBM bytes per launch at 65,536 instances from the committed PMC passes (2 * FETCH_SIZE + WRITE_SIZE, KB -> bytes)
+PMC = {
+    "admm": ((2 * 49314.40 + 213303.90) * 1024.0, "profiles/r01_v5_pmc.csv (admm_shared_box_kernel)"),
+    "pass_a": ((2 * 7200.65 + 185924.27) * 1024.0, "profiles/r01_v7_pmc.csv (first polish_oct_kernel launch)"),
+}
 
 
-def cpu_baseline(prob, seconds=15.0):
-    """Time the C restatement of the reference's solver class (oracle/qp_ipm.c: dense Mehrotra
-    IPM on (P,q,G,h) with cvxopt's default tolerances, one QP per thread) on a bounded sample of
-    the SAME workload, on this box's host cores.  Checker/baseline only -- never the product."""
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None, help="default 50 (1000 for --config 4)")
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", type=int, default=3, choices=[2, 3, 4, 5],
+                    help="BASELINE.json configs[c-1]; 3 = the headline workload")
+    ap.add_argument("--batch", type=int, default=None, help="GLOBAL batch (strong) / per-GPU batch (weak); default per config")
+    ap.add_argument("--scaling", choices=["strong", "weak"], default="strong")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-shard-sweep", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--max-iter", type=int, default=None)
+    ap.add_argument("--rho", type=float, default=None)
+    args = ap.parse_args(argv)
+    if args.steps is None:
+        args.steps = 1000 if args.config == 4 else 50
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    return args
+
+
+# ---- launcher: runs in a process that never touches the GPU -------------------------------------------------------------
+def launch_command(gpus, argv, port, python=sys.executable):
+    """The command line of the N-rank job (one rank per GPU, rendezvous on 127.0.0.1)."""
+    return [python, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def launch_env(gpus, n_devices, environ):
+    """Environment of the ranks.  Fewer devices than ranks (the one-GPU development box) selects the REHEARSAL mode: the
+    ranks share devices and the collectives run on host tensors over gloo -- the same code path, no RCCL."""
+    env = dict(environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    if n_devices < gpus:
+        env.setdefault("MPC_BENCH_BACKEND", "gloo")
+    return env
+
+
+def needs_launch(args, environ):
+    return args.gpus > 1 and "WORLD_SIZE" not in environ
+
+
+def launch(args, argv):
+    import torch            # counting devices does not initialise HIP; nothing else of torch.cuda is called here
+    ndev = torch.cuda.device_count()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = launch_command(args.gpus, argv, port)
+    # children are fresh processes (never an exec of this one); stdout is inherited, so rank 0's JSON line is ours
+    return subprocess.call(cmd, env=launch_env(args.gpus, ndev, os.environ))
+
+
+# ---- CPU baselines (oracle/: checker and baseline only, never the product) ----------------------------------------------
+def _host_cores():
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        cores = int(os.environ["OMP_NUM_THREADS"])
+    return max(1, min(cores, 16))
+
+
+def cpu_baseline_box(prob, seconds, what):
+    """oracle/qp_ipm.c (dense Mehrotra IPM on (P,q,G,h), cvxopt's default tolerances, one QP per thread) and
+    oracle/qp_activeset.c (the GPU's own algorithm, exact) on a bounded sample of the SAME workload."""
+    import numpy as np
     from oracle import cpu_baseline as cb
     from oracle import mpc_oracle as mo
     H, F, f0 = mo.condense(prob)
     lb = np.tile(prob["u_min"], prob["N"]); ub = np.tile(prob["u_max"], prob["N"])
-    cores = min(16, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else os.cpu_count())
-    cores = int(os.environ.get("OMP_NUM_THREADS", cores)) if os.environ.get("OMP_NUM_THREADS", "").isdigit() else cores
-    cores = max(1, min(cores, 16))
-    # calibrate on 64 instances single-thread, then size the sample to ~`seconds` of wall time
+    cores = _host_cores()
     _, _, _, t1 = cb.solve_batch_box(H, F, f0, lb, ub, prob["x0"][:64], nthreads=1)
     per_core = 64 / t1
     nsamp = int(min(len(prob["x0"]), max(256, per_core * cores * seconds)))
     U, it, bad, t = cb.solve_batch_box(H, F, f0, lb, ub, prob["x0"][:nsamp], nthreads=cores)
-    return {"value": nsamp / t, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"first {nsamp} of the 65,536 x0 (same H,F,bounds); dense Mehrotra IPM, cvxopt default "
-                      f"tolerances, mean {float(it.mean()):.1f} iterations, {bad} not optimal; "
-                      f"single-core {per_core:.0f} solves/s",
-            "single_core": per_core}
+    out = {"value": nsamp / t, "unit": "solves/s", "cores": cores, "kind": "port",
+           "sample": f"first {nsamp} of the {len(prob['x0'])} x0 of {what} (same H,F,bounds); dense Mehrotra IPM, cvxopt "
+                     f"default tolerances, mean {float(it.mean()):.1f} iterations, {bad} not optimal; "
+                     f"single-core {per_core:.0f} solves/s",
+           "single_core": per_core}
+    if hasattr(cb, "solve_batch_box_activeset"):
+        try:
+            ns2 = int(min(len(prob["x0"]), 8 * nsamp))
+            _, st2, bad2, t2 = cb.solve_batch_box_activeset(H, F, f0, lb, ub, prob["x0"][:ns2], nthreads=cores)
+            out["same_algorithm"] = {"value": ns2 / t2, "unit": "solves/s", "cores": cores,
+                                     "what": "dual active-set method on the shared inverse (the GPU's algorithm, exact "
+                                             f"minimiser) in C, OpenMP; first {ns2} x0, mean {float(st2.mean()):.1f} "
+                                             f"steps, {bad2} failed"}
+        except Exception as e:      # noqa: BLE001
+            out["same_algorithm"] = {"value": None, "what": f"failed: {e!r}"}
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
-    ap.add_argument("--max-iter", type=int, default=None)
-    ap.add_argument("--rho", type=float, default=None)
-    args = ap.parse_args()
+# ---- collectives ---------------------------------------------------------------------------------------------------------
+class Ranks:
+    """One rank per GPU.  backend "nccl" = RCCL on device tensors; "gloo" (MPC_BENCH_BACKEND, rehearsal on a box with
+    fewer GPUs than ranks) = host tensors."""
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU over RCCL; MPC_BENCH_BACKEND=gloo with several ranks on ONE device is only a rehearsal of
-        # this code path on a single-GPU box
-        backend = os.environ.get("MPC_BENCH_BACKEND", "nccl")
-        local = local % max(1, torch.cuda.device_count())
-        torch.cuda.set_device(local)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
-        else:
-            dist.init_process_group(backend)
-    else:
-        torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-    verbose = bool(os.environ.get("MPC_BENCH_VERBOSE"))
+    def __init__(self):
+        import torch
+        self.torch = torch
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.dist = None
+        self.backend = None
+        ndev = max(1, torch.cuda.device_count())
+        self.local = local % ndev
+        torch.cuda.set_device(self.local)
+        self.dev = torch.device(f"cuda:{self.local}")
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            self.backend = os.environ.get("MPC_BENCH_BACKEND", "nccl")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+            self.dist = dist
+        self.cdev = self.dev if self.backend in (None, "nccl") else torch.device("cpu")
+        self._bar = torch.zeros(1, dtype=torch.int32, device=self.cdev)
+        self._flags = [torch.zeros(1, dtype=torch.int32, device=self.cdev) for _ in range(2)]
+        self._pending = None
+        self._n = 0
+        self.all_ok = True
 
-    def note(msg):
-        if verbose:
-            print(f"[rank {rank}] {msg}", file=sys.stderr, flush=True)
+    def barrier(self):
+        # an all-reduce of one int synchronises the ranks on every backend (torch's gloo barrier() hung on the rehearsal
+        # box in round 1; RCCL's own barrier is this all-reduce)
+        if self.dist is not None:
+            self.dist.all_reduce(self._bar)
+            if self.cdev.type == "cuda":
+                self.torch.cuda.synchronize(self.dev)
 
-    from mpc_amd.configs import make_config
-    from mpc_amd.planner import Planner
+    def flag_allreduce(self, ok_dev):
+        """all-reduce(MIN) of this step's all-solved flag; the reduce of step i is in flight while step i+1 computes
+        (two buffers); drain() ends the timed region, so every collective is inside it."""
+        if self.dist is None:
+            return
+        f = self._flags[self._n & 1]
+        self._n += 1
+        # RCCL: device-to-device copy, ordered on the compute stream, which the collective's stream waits for.
+        # gloo: a BLOCKING copy to the host tensor -- it must have landed before the collective reads it.
+        f.copy_(ok_dev)
+        self.drain()
+        self._pending = (self.dist.all_reduce(f, op=self.dist.ReduceOp.MIN, async_op=True), f)
 
-    B = args.batch
-    prob = make_config(3, batch=B, seed=rank)       # every rank draws its own x0 shard
-    pl = Planner(prob["nx"], prob["nu"], prob["N"], device=dev)
-    pl.set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
-    pl.set_constraints(prob["u_min"], prob["u_max"])
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    pl.setup(rho=args.rho)
-    torch.cuda.synchronize(dev)
-    setup_ms = (time.perf_counter() - t0) * 1e3
-    x0 = torch.as_tensor(prob["x0"], device=dev)
-    opts = {}
-    if args.max_iter is not None:
-        opts["max_iter"] = args.max_iter
-    # collectives run on device tensors over RCCL; a rehearsal backend (gloo) gets host tensors
-    cdev = dev if (dist is None or dist.get_backend() == "nccl") else torch.device("cpu")
-    flag = torch.zeros(1, dtype=torch.int32, device=cdev)
-    bar = torch.zeros(1, dtype=torch.int32, device=cdev)
+    def drain(self):
+        if self._pending is not None:
+            work, f = self._pending
+            work.wait()
+            self._pending = None
+            self._last_flag = f
 
-    def barrier():
-        # RCCL: the library's barrier; rehearsal backends: an all-reduce, which synchronises the ranks just the same
-        if dist.get_backend() == "nccl":
-            dist.barrier()
-        else:
-            dist.all_reduce(bar)
+    def max_over_ranks(self, seconds):
+        if self.dist is None:
+            return seconds
+        t = self.torch.tensor([seconds], dtype=self.torch.float64, device=self.cdev)
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
 
-    flags = [flag, flag.clone()]
-    pending = [None]
-    nstep = [0]
+    def finish(self):
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()
 
-    def step():
-        # the all-reduce of the all-solved flag of step i is in flight while step i+1 computes (two flag buffers);
-        # the timed region ends with drain() + barrier, so every collective is inside it
-        U = pl.solve(x0, **opts)
-        if dist is not None:
-            f = flags[nstep[0] & 1]
-            nstep[0] += 1
-            f.copy_((pl.info.status == 0).all().to(torch.int32).reshape(1), non_blocking=True)
-            if pending[0] is not None:
-                pending[0].wait()
-            pending[0] = dist.all_reduce(f, op=dist.ReduceOp.MIN, async_op=True)
-        return U
 
-    def drain():
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
-
-    note("setup done")
-    for _ in range(args.warmup):
-        U = step()
-    drain()
-    note("warmup done")
-    if dist is not None:
-        barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        U = step()
-    drain()
-    if dist is not None:
-        barrier()
-    torch.cuda.synchronize(dev)
-    dt = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-
-    note("timed region done")
-    info = pl.info
-    n_solved = int((info.status == 0).sum().item())
-    iters_mean = float(info.iters.float().mean().item())
-    iters_max = int(info.iters.max().item())
-    psteps_mean = float(info.polish_steps.float().mean().item())
-    psteps_max = int(info.polish_steps.max().item())
-
-    # ---- per-kernel device time with events on the stream the kernels run on (torch's current stream)
+def device_timer(torch, dev):
+    """ms per call from events on the stream the kernels are launched on (the Planner uses torch's current stream)."""
     def timed(fn, reps):
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         fn(); torch.cuda.synchronize(dev)
@@ -184,99 +219,392 @@ def main():
         for _ in range(reps):
             fn()
         e1.record(); torch.cuda.synchronize(dev)
-        return e0.elapsed_time(e1) / reps       # ms
+        return e0.elapsed_time(e1) / reps
+    return timed
 
-    reps = max(5, min(args.steps, 20))
-    admm_on = iters_max > 0
-    admm_ms = timed(lambda: pl.solve(x0, stages=1, **opts), reps) if admm_on else 0.0
-    both_ms = timed(lambda: pl.solve(x0, **opts), reps)
-    polish_ms = max(both_ms - admm_ms, 0.0)
-    # the first (and longest) active-set launch alone: stages bit 2 stops after it (diagnostic; queued instances stay open)
-    # (bit 3: after the cold-start ordering kernels, which run before it)
-    order_ms = max(timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms, 0.0)
-    pass_a_ms = max(timed(lambda: pl.solve(x0, stages=7, **opts), reps) - admm_ms - order_ms, 0.0)
-    # p50 / p99 of single-batch solve latency: one event pair per solve
-    lat = []
-    nlat = max(20, min(args.steps, 100))
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlat)]
-    for e0, e1 in evs:
-        e0.record(); pl.solve(x0, **opts); e1.record()
+
+# ---- workloads -------------------------------------------------------------------------------------------------------------
+class BoxWorkload:
+    """configs[1] (cart-pole) and configs[2] (quadrotor, the headline): shared LTI model, box-constrained inputs."""
+
+    def __init__(self, args, ranks):
+        import torch
+        from mpc_amd.configs import make_config
+        from mpc_amd.distributed import shard_range
+        from mpc_amd.planner import Planner
+        self.args, self.ranks, self.torch = args, ranks, torch
+        cfg = args.config
+        default_batch = {2: 4096, 3: 65536}[cfg]
+        G = args.batch or default_batch
+        if args.scaling == "strong":
+            self.global_batch = G
+            self.prob = make_config(cfg, batch=G, seed=0)           # every rank draws the SAME global set ...
+            lo, hi = shard_range(G, ranks.rank, ranks.world)        # ... and solves its contiguous row block
+        else:
+            self.global_batch = G * ranks.world
+            self.prob = make_config(cfg, batch=G, seed=ranks.rank)  # every rank draws its own shard
+            lo, hi = 0, G
+        prob = self.prob
+        self.B = hi - lo
+        dev = ranks.dev
+        self.pl = pl = Planner(prob["nx"], prob["nu"], prob["N"], device=dev)
+        pl.set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+        pl.set_constraints(prob["u_min"], prob["u_max"])
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pl.setup(rho=args.rho)
+        torch.cuda.synchronize(dev)
+        self.setup_ms = (time.perf_counter() - t0) * 1e3
+        self.x0_all = torch.as_tensor(prob["x0"], device=dev)
+        self.x0 = self.x0_all[lo:hi].contiguous()
+        self.opts = {} if args.max_iter is None else {"max_iter": args.max_iter}
+        self.U = None
+        self.units_per_step = self.global_batch
+        self.name = {2: "configs[1]: cart-pole linearised MPC nx=4 nu=1 N=50 (n=50 box-constrained QP)",
+                     3: "configs[2]: quadrotor hover MPC nx=12 nu=4 N=30 (n=120 box-constrained QP)"}[cfg]
+
+    def step(self):
+        self.U = self.pl.solve(self.x0, **self.opts)
+        if self.ranks.dist is not None:
+            self.ranks.flag_allreduce((self.pl.info.status == 0).all().to(self.torch.int32).reshape(1))
+
+    def report(self, dt):
+        args, ranks, torch, pl, prob = self.args, self.ranks, self.torch, self.pl, self.prob
+        dev, B, x0, opts = ranks.dev, self.B, self.x0, self.opts
+        timed = device_timer(torch, dev)
+        info = pl.info
+        n_solved = int((info.status == 0).sum().item())
+        iters_mean = float(info.iters.float().mean().item()); iters_max = int(info.iters.max().item())
+        psteps_mean = float(info.polish_steps.float().mean().item()); psteps_max = int(info.polish_steps.max().item())
+        reps = max(5, min(args.steps, 20))
+        admm_on = iters_max > 0
+        admm_ms = timed(lambda: pl.solve(x0, stages=1, **opts), reps) if admm_on else 0.0
+        both_ms = timed(lambda: pl.solve(x0, **opts), reps)
+        # the first (and longest) active-set launch alone: stages bit 2 stops after it, bit 3 after the cold-start
+        # ordering kernels that run before it (diagnostic modes: queued instances stay open)
+        order_ms = max(timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms, 0.0)
+        pass_a_ms = max(timed(lambda: pl.solve(x0, stages=7, **opts), reps) - admm_ms - order_ms, 0.0)
+        nlat = max(20, min(args.steps, 100))
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlat)]
+        for e0, e1 in evs:
+            e0.record(); pl.solve(x0, **opts); e1.record()
+        torch.cuda.synchronize(dev)
+        lat = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        p50_ms, p99_ms = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.99 * len(lat)))]
+
+        allgather_ms = None
+        if ranks.dist is not None and ranks.cdev == dev and args.scaling == "strong":
+            from mpc_amd.distributed import allgather_solutions
+            allgather_ms = timed(lambda: allgather_solutions(self.U, self.global_batch), 5)
+
+        # shard sizes of the 2/4/8-GPU split of the same batch, on THIS GPU: what strong scaling will be made of
+        sweep = None
+        if ranks.world == 1 and not args.no_shard_sweep and args.config == 3:
+            sweep = {}
+            for div in (1, 2, 4, 8):
+                b = self.global_batch // div
+                xs = self.x0_all[:b].contiguous()
+                sweep[str(b)] = timed(lambda: pl.solve(xs, **opts), reps)
+            t1, t8 = sweep[str(self.global_batch)], sweep[str(self.global_batch // 8)]
+            sweep["implied_strong_efficiency_8"] = t1 / (8.0 * t8)
+            pl.solve(x0, **opts)
+
+        n = pl.n
+        if admm_on:
+            flops = B * iters_mean * (2 * n * n + 10 * (n + n))         # SURVEY.md 8(d): 2 n^2 + 10 (n + m) per iteration
+            tf = flops / (admm_ms * 1e-3) / 1e12
+            roofline = {"bound": "mfma", "kernel": "admm_shared_box_kernel", "achieved": tf, "peak": FP64_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": PMC["admm"][0] * B / 65536.0,
+                        "traffic_source": PMC["admm"][1] + ", scaled with the batch",
+                        "algorithmic_bytes": B * (8 * prob["nx"] + 3 * 8 * 16 * ((n + 15) // 16)),
+                        "flops_per_launch": flops, "launch_ms": admm_ms}
+        else:
+            # first active-set pass.  Algorithmic bytes per instance: x0 in; U, the (z, w) warm-start state and the info
+            # record out.  It is NOT a streaming kernel (a dependent chain of fp64 steps per instance, DESIGN.md
+            # section 4): the HBM fraction is reported because the contract offers no third bound
+            pa_bytes = B * (8 * prob["nx"] + 8 * n + 2 * 8 * n + 36)
+            gbs = pa_bytes / (pass_a_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "kernel": "polish_oct_kernel (first active-set pass)", "achieved": gbs,
+                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                        "traffic": PMC["pass_a"][0] * B / 65536.0 if args.config == 3 else None,
+                        "traffic_source": PMC["pass_a"][1] + ", scaled with the batch" if args.config == 3 else None,
+                        "algorithmic_bytes": pa_bytes, "launch_ms": pass_a_ms,
+                        "note": "latency / VALU-issue bound by construction: ~8 dependent active-set steps per instance in "
+                                "fp64; VALU busy fraction and instruction counts in DESIGN.md section 4"}
+        config = {"workload": f"{self.name}, {self.global_batch} random x0 "
+                              f"{'split over' if args.scaling == 'strong' else 'per GPU on'} {ranks.world} GPU(s), "
+                              "shared LTI model",
+                  "batch_per_gpu": B, "global_batch": self.global_batch,
+                  "parallelism": f"dp{ranks.world} (independent shards, no data-path collective)",
+                  "algorithm": ("ADMM (shared (Hs+rho I)^-1, fp64 MFMA GEMM form) + " if admm_on else "") +
+                               "dual active-set kernels (8/32 lanes per instance, explicit S^-1 in registers, Hs^-1 in LDS)",
+                  "admm_iters_mean": iters_mean, "admm_iters_max": iters_max,
+                  "polish_steps_mean": psteps_mean, "polish_steps_max": psteps_max,
+                  "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": self.setup_ms,
+                  "p50_batch_latency_ms": p50_ms, "p99_batch_latency_ms": p99_ms, "mean_batch_latency_ms": both_ms,
+                  "admm_kernel_ms": admm_ms, "polish_kernels_ms": max(both_ms - admm_ms, 0.0),
+                  "first_pass_ms": pass_a_ms, "cold_order_ms": order_ms,
+                  "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if ranks.world > 1 else "none",
+                  "collective_backend": ranks.backend, "allgather_ms": allgather_ms, "shard_sweep_ms": sweep,
+                  "hbm_GBps_compulsory": B * (8 * prob["nx"] + 8 * n + 16 + 4 * 8 * n) / (both_ms * 1e-3) / 1e9}
+        return config, roofline
+
+    def cpu_baseline(self):
+        return cpu_baseline_box(self.prob, self.args.cpu_seconds, self.name.split(":")[0])
+
+
+class LtvWorkload:
+    """configs[3]: kinematic-bicycle LTV closed loop with warm-start shifting; one model per rollout, re-linearised,
+    assembled, factored and solved every step.  One step = one closed-loop step of every rollout = `rollouts` QPs."""
+
+    def __init__(self, args, ranks):
+        import torch
+        from mpc_amd.configs import make_config
+        from mpc_amd.distributed import shard_range
+        from mpc_amd.ltv import Bicycle, ClosedLoopLTV
+        self.args, self.ranks, self.torch = args, ranks, torch
+        G = args.batch or 8192
+        if args.scaling == "strong":
+            self.global_batch = G
+            cfg = make_config(4, batch=G, seed=0)
+            lo, hi = shard_range(G, ranks.rank, ranks.world)
+        else:
+            self.global_batch = G * ranks.world
+            cfg = make_config(4, batch=G, seed=ranks.rank)
+            lo, hi = 0, G
+        self.cfg = cfg
+        self.B = hi - lo
+        dev = ranks.dev
+        self.N, self.dt = cfg["N"], cfg["dt"]
+        self.loop = ClosedLoopLTV(Bicycle(cfg["L"], self.dt), self.N, cfg["Q"], cfg["R"], cfg["P"], cfg["u_min"],
+                                  cfg["u_max"], device=dev)
+        self.x = torch.as_tensor(cfg["x0"][lo:hi], device=dev).contiguous()
+        self.ks = torch.arange(1, self.N + 1, device=dev, dtype=torch.float64)
+        self.x_ref = torch.zeros((self.B, self.N, 4), dtype=torch.float64, device=dev)
+        self.x_ref[:, :, 3] = cfg["v_ref"]
+        self.units_per_step = self.global_batch
+        self.setup_ms = 0.0
+        self.nsteps = 0
+
+    def step(self):
+        cfg = self.cfg
+        self.x_ref[:, :, 0] = self.x[:, :1] + cfg["v_ref"] * self.dt * self.ks
+        u0 = self.loop.step(self.x, self.x_ref, warm=True)
+        self.x = self.loop.model.step(self.x, u0)
+        self.nsteps += 1
+        if self.ranks.dist is not None:
+            self.ranks.flag_allreduce((self.loop.pl.info.status == 0).all().to(self.torch.int32).reshape(1))
+
+    def report(self, dt):
+        import ctypes as C
+        args, ranks, torch = self.args, self.ranks, self.torch
+        dev = ranks.dev
+        pl = self.loop.pl
+        timed = device_timer(torch, dev)
+        info = pl.info
+        solved = float((info.status == 0).float().mean().item())
+        st_mean = float(info.polish_steps.float().mean().item())
+        # per-kernel device time of one step's library calls, on the data of the last step
+        stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        lib, h = pl._lib, pl._h
+        from mpc_amd import _lib
+        fo = _lib.FactorOpts(0.0, 1, 1)
+        asm_ms = timed(lambda: lib.mpcqp_assemble(h, stream), 20)
+        fac_ms = timed(lambda: (lib.mpcqp_assemble(h, stream), lib.mpcqp_factor(h, C.byref(fo), stream)), 20) - asm_ms
+        nx, nu, N = 4, 2, self.N
+        n, p = N * nu, N * nx
+        # SURVEY.md 8(d) assembly flops per distinct system: rollout + Qbar Gamma (block lower triangular) + H as SYRK + F
+        flops = (2 * nx ** 3 * N + 2 * nx * nx * nu * (N - 1)) + 2 * nx * nx * nu * N * (N + 1) // 2 + p * n * (n + 1) \
+            + 2 * n * p * nx
+        tf = self.B * flops / (asm_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "assemble_kernel (one workgroup per rollout's model)", "achieved": tf,
+                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
+                    "flops_per_launch": self.B * flops, "launch_ms": asm_ms,
+                    "note": "n = 40: tiles are too small for the MFMA peak; the kernel is bound by its own Gamma / Qbar Gamma "
+                            "traffic and the serial N-step chain (DESIGN.md section 4)"}
+        config = {"workload": f"configs[3]: kinematic-bicycle LTV MPC closed loop nx=4 nu=2 N={N} (n={n}), "
+                              f"{self.global_batch} parallel rollouts over {ranks.world} GPU(s), warm-start shifting, every "
+                              "rollout re-linearised, assembled, factored and solved each step",
+                  "batch_per_gpu": self.B, "global_batch": self.global_batch, "closed_loop_steps": args.steps,
+                  "parallelism": f"dp{ranks.world} (independent rollouts)",
+                  "ms_per_closed_loop_step": dt / args.steps * 1e3, "assemble_ms": asm_ms, "factor_ms": fac_ms,
+                  "active_set_steps_mean_last": st_mean, "solved_fraction_last": solved,
+                  "final_abs_y_max": float(self.x[:, 1].abs().max().item()),
+                  "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if ranks.world > 1 else "none",
+                  "collective_backend": ranks.backend}
+        return config, roofline
+
+    def cpu_baseline(self):
+        """The same closed-loop QP on the host: NumPy condensing (oracle/mpc_oracle.py) + the C IPM per rollout, on a
+        sample of the rollouts of the last step (same linearisation data, read back from the device)."""
+        import numpy as np
+        from oracle import cpu_baseline as cb
+        from oracle import mpc_oracle as mo
+        last = self.loop.last
+        cores = _host_cores()
+        ns = min(self.B, 64 * cores)
+        A = last["A"][:ns].cpu().numpy(); Bm = last["B"][:ns].cpu().numpy()
+        buf = self.loop._buf
+        xr = buf["xr"][:ns].cpu().numpy(); ur = buf["ur"][:ns].cpu().numpy()
+        lb = buf["lb"][:ns].cpu().numpy().reshape(ns, -1); ub = buf["ub"][:ns].cpu().numpy().reshape(ns, -1)
+        cfg = self.cfg
+        t0 = time.perf_counter()
+        bad = 0
+        for i in range(ns):
+            prob = dict(N=self.N, nx=4, nu=2, A=A[i], B=Bm[i], Q=cfg["Q"], R=cfg["R"], P=cfg["P"])
+            H, F, f0 = mo.condense(prob, x_ref=xr[i], u_ref=ur[i])
+            _, _, b, _ = cb.solve_batch_box(H, F, f0, lb[i], ub[i], np.zeros((1, 4)), nthreads=1)
+            bad += b
+        t = time.perf_counter() - t0
+        return {"value": ns / t, "unit": "solves/s", "cores": 1, "kind": "port",
+                "sample": f"{ns} rollouts of the last closed-loop step: NumPy condensing + C Mehrotra IPM per rollout, "
+                          f"single thread, {bad} not optimal"}
+
+
+class RowsWorkload:
+    """configs[4]: long horizon N=100, nx=20, nu=6 (n=600) with input box + state box + polytopic rows (13,200 one-sided
+    rows), shared model, constraint-space active-set kernel."""
+
+    def __init__(self, args, ranks):
+        import torch
+        from mpc_amd.configs import make_config
+        from mpc_amd.distributed import shard_range
+        from mpc_amd.planner import Planner
+        self.args, self.ranks, self.torch = args, ranks, torch
+        G = args.batch or 256
+        if args.scaling == "strong":
+            self.global_batch = G
+            prob = make_config(5, batch=G, seed=0)
+            lo, hi = shard_range(G, ranks.rank, ranks.world)
+        else:
+            self.global_batch = G * ranks.world
+            prob = make_config(5, batch=G, seed=ranks.rank)
+            lo, hi = 0, G
+        self.prob = prob
+        self.B = hi - lo
+        dev = ranks.dev
+        self.pl = pl = Planner(prob["nx"], prob["nu"], prob["N"], device=dev)
+        pl.set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+        pl.set_constraints(prob["u_min"], prob["u_max"], x_min=prob["x_min"], x_max=prob["x_max"], C=prob["C"],
+                           c_min=prob["c_min"], c_max=prob["c_max"])
+        self.x0 = torch.as_tensor(prob["x0"][lo:hi], device=dev).contiguous()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        pl.setup()
+        pl.solve(self.x0[:1])           # the Gram set-up runs with the first solve
+        torch.cuda.synchronize(dev)
+        self.setup_ms = (time.perf_counter() - t0) * 1e3
+        self.units_per_step = self.global_batch
+
+    def step(self):
+        self.U = self.pl.solve(self.x0)
+        if self.ranks.dist is not None:
+            self.ranks.flag_allreduce((self.pl.info.status == 0).all().to(self.torch.int32).reshape(1))
+
+    def report(self, dt):
+        args, ranks, torch, pl, prob = self.args, self.ranks, self.torch, self.pl, self.prob
+        timed = device_timer(torch, ranks.dev)
+        info = pl.info
+        n, m = pl.n, int(pl._gen["G"].shape[0])
+        steps = info.polish_steps.double()
+        k_mean, k_max = float(steps.mean().item()), int(steps.max().item())
+        solve_ms = timed(lambda: pl.solve(self.x0), 10)
+        # algorithmic bytes of the active-set kernel per instance (DESIGN.md section 4): step s reads s+1 rows of the
+        # dual Hessian and reads + writes the m row residuals; the arg-max pass reads them once more
+        per_inst = float((8.0 * m * (steps * (steps + 1) / 2 + 4 * steps)).mean().item()) + 8.0 * (3 * n * n + 2 * m)
+        gbs = self.B * per_inst / (solve_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": "rows_qp_kernel + its GEMM prologue (whole mpcqp_rows_solve_mpc call)",
+                    "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                    "algorithmic_bytes": self.B * per_inst, "launch_ms": solve_ms}
+        config = {"workload": f"configs[4]: long-horizon MPC nx={prob['nx']} nu={prob['nu']} N={prob['N']} (n={n}, {m} one-sided "
+                              f"rows: input box + state box + polytope), {self.global_batch} x0 over {ranks.world} GPU(s), "
+                              "shared model",
+                  "batch_per_gpu": self.B, "global_batch": self.global_batch, "path": pl.general_path,
+                  "parallelism": f"dp{ranks.world} (independent shards)", "setup_ms": self.setup_ms,
+                  "active_set_steps_mean": k_mean, "active_set_steps_max": k_max,
+                  "solved_fraction": float((info.status == 0).float().mean().item()), "batch_latency_ms": solve_ms,
+                  "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if ranks.world > 1 else "none",
+                  "collective_backend": ranks.backend}
+        return config, roofline
+
+    def cpu_baseline(self):
+        import numpy as np
+        from oracle import cpu_baseline as cb
+        pl = self.pl
+        g = pl._gen
+        H = g["H"].cpu().numpy(); F = g["F"].cpu().numpy(); f0 = g["f0"].cpu().numpy()
+        G = g["G"].cpu().numpy(); E = g["E"].cpu().numpy(); h0 = g["h0"].cpu().numpy()
+        x0 = self.prob["x0"]
+        from concurrent.futures import ThreadPoolExecutor
+        cores = _host_cores()
+        ns = min(cores, len(x0))            # one instance per thread (ctypes releases the GIL), ~30 s each at full size
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            res = list(ex.map(lambda i: cb.solve_dense(H, F @ x0[i] + f0, G, h0 - E @ x0[i]), range(ns)))
+        t = time.perf_counter() - t0
+        bad = sum(int(r[2] != 0) for r in res)
+        return {"value": ns / t, "unit": "solves/s", "cores": cores, "kind": "port",
+                "sample": f"{ns} of the {len(x0)} instances (n={H.shape[0]}, {G.shape[0]} rows), one per thread: C Mehrotra "
+                          f"IPM, cvxopt default tolerances, mean {np.mean([r[3] for r in res]):.1f} iterations, "
+                          f"{bad} not optimal"}
+
+
+WORKLOADS = {2: BoxWorkload, 3: BoxWorkload, 4: LtvWorkload, 5: RowsWorkload}
+METRIC = {2: "QP solves/sec at batch 4,096, nx=4 nu=1 N=50 (cart-pole)",
+          3: "QP solves/sec (node) at batch 65,536, nx=12 nu=4 N=30",
+          4: "QP solves/sec, kinematic-bicycle LTV closed loop, 8,192 rollouts",
+          5: "QP solves/sec, long-horizon N=100 nx=20 nu=6 with state box + polytopic rows"}
+
+
+def run_rank(args):
+    import torch
+    ranks = Ranks()
+    dev = ranks.dev
+    verbose = bool(os.environ.get("MPC_BENCH_VERBOSE"))
+
+    def note(msg):
+        if verbose:
+            print(f"[rank {ranks.rank}] {msg}", file=sys.stderr, flush=True)
+
+    wl = WORKLOADS[args.config](args, ranks)
+    note("setup done")
+    for _ in range(args.warmup):
+        wl.step()
+    ranks.drain()
+    note("warmup done")
+    ranks.barrier()
     torch.cuda.synchronize(dev)
-    lat = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
-    p50_ms, p99_ms = lat[len(lat) // 2], lat[min(len(lat) - 1, int(0.99 * len(lat)))]
-
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        wl.step()
+    ranks.drain()
+    ranks.barrier()
+    torch.cuda.synchronize(dev)
+    dt = ranks.max_over_ranks(time.perf_counter() - t0)
+    note("timed region done")
+    config, roofline = wl.report(dt)
     note("per-kernel timing done")
-    allgather_ms = None
-    if dist is not None and cdev == dev:
-        gathered = torch.empty((world,) + tuple(U.shape), dtype=U.dtype, device=dev)
-        allgather_ms = timed(lambda: dist.all_gather_into_tensor(gathered, U), 5)
-
-    # ---- roofline of the dominant kernel (the ADMM kernel), SURVEY.md section 8(d) counts:
-    # flops/iteration/instance = 2 n^2 + 10 (n + m), m = n box rows, times the iterations executed
-    n = pl.n
-    flops_per_iter = 2 * n * n + 10 * (n + n)
-    admm_flops = B * iters_mean * flops_per_iter
-    achieved_tf = admm_flops / (admm_ms * 1e-3) / 1e12 if admm_on else 0.0
-    # compulsory HBM bytes per solve: x0 in, U + info out, plus the (z, w) state the kernels exchange
-    hbm_bytes_per_solve = 8 * prob["nx"] + 8 * n + 16 + 4 * 8 * pl.n
-    hbm_gbs = B * hbm_bytes_per_solve / (both_ms * 1e-3) / 1e9
-
-    if admm_on:
-        roofline = {"bound": "mfma", "kernel": "admm_shared_box_kernel<8,30>", "achieved": achieved_tf,
-                    "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved_tf / FP64_PEAK_TFLOPS,
-                    # HBM bytes per launch from the PMC passes committed under profiles/ (rocprofv3 --pmc FETCH_SIZE and
-                    # WRITE_SIZE in separate runs; FETCH doubled as the gfx950 guide prescribes), measured at 65,536
-                    # instances and scaled with the batch; not re-measured by this script
-                    "traffic": ADMM_TRAFFIC_BYTES_65536 * B / 65536.0,
-                    "traffic_source": "profiles/r01_v5_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of admm_shared_box_kernel)",
-                    "algorithmic_bytes": B * (8 * prob["nx"] + 3 * 8 * 16 * ((n + 15) // 16)),
-                    "flops_per_launch": admm_flops, "launch_ms": admm_ms}
-    else:
-        # default: no ADMM launch; the dominant kernel is the first active-set pass.  Its algorithmic bytes per instance:
-        # x0 in; U, the (z, w) warm-start state and the info record out.  It is NOT an HBM-streaming kernel: a dependent
-        # chain of fp64 VALU steps per instance -- the fraction is reported as the contract asks
-        pa_bytes = B * (8 * prob["nx"] + 8 * n + 2 * 8 * n + 36)
-        pa_gbs = pa_bytes / (pass_a_ms * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "polish_oct_kernel<8,8,16,512> (first active-set pass)", "achieved": pa_gbs,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": pa_gbs / HBM_PEAK_GBS,
-                    "traffic": POLISH_A_TRAFFIC_BYTES_65536 * B / 65536.0,
-                    "traffic_source": "profiles/r01_v7_pmc.csv (2*FETCH_SIZE + WRITE_SIZE of the first polish_oct_kernel launch)",
-                    "algorithmic_bytes": pa_bytes, "launch_ms": pass_a_ms,
-                    "note": "latency/VALU bound by construction: ~8 dependent active-set steps per instance in fp64; "
-                            "VALU busy fraction and instruction counts in DESIGN.md"}
-    out = None
-    if rank == 0:
-        total = world * B * args.steps
-        out = {
-            "metric": "QP solves/sec (node) at batch 65,536, nx=12 nu=4 N=30",
-            "value": total / dt, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "configs[2]: quadrotor hover MPC nx=12 nu=4 N=30 (n=120 box-constrained QP), "
-                                   f"{B} random x0 per GPU, shared LTI model",
-                       "batch_per_gpu": B, "global_batch": world * B, "parallelism": f"dp{world} (independent shards)",
-                       "algorithm": ("ADMM (shared (Hs+rho I)^-1, fp64 MFMA GEMM form) + " if admm_on else "") +
-                                    "dual active-set kernels (8/16 lanes per instance, explicit S^-1 in registers, Hs^-1 in LDS)",
-                       "admm_iters_mean": iters_mean, "admm_iters_max": iters_max,
-                       "polish_steps_mean": psteps_mean, "polish_steps_max": psteps_max,
-                       "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": setup_ms,
-                       "p50_batch_latency_ms": p50_ms, "p99_batch_latency_ms": p99_ms, "mean_batch_latency_ms": both_ms, "admm_kernel_ms": admm_ms, "polish_kernels_ms": polish_ms,
-                       "first_pass_ms": pass_a_ms, "cold_order_ms": order_ms,
-                       "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if world > 1 else "none",
-                       "allgather_ms": allgather_ms,
-                       "hbm_GBps_compulsory": hbm_gbs, "hbm_frac": hbm_gbs / HBM_PEAK_GBS},
-            "roofline": roofline,
-        }
-        if world == 1 and not args.no_cpu_baseline:
+    if ranks.rank == 0:
+        out = {"metric": METRIC[args.config], "value": wl.units_per_step * args.steps / dt, "unit": "solves/s",
+               "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+               "config": config, "roofline": roofline}
+        if ranks.world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(prob, args.cpu_seconds)
-            except Exception as e:      # the baseline is a report, never a reason to lose the GPU line
+                out["cpu_baseline"] = wl.cpu_baseline()
+            except Exception as e:      # noqa: BLE001 -- the baseline is a report, never a reason to lose the GPU line
                 out["cpu_baseline"] = {"value": None, "unit": "solves/s", "cores": 0, "kind": "port",
                                        "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        barrier()
-        dist.destroy_process_group()
+    ranks.finish()
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else list(argv)
+    args = parse_args(argv)
+    if needs_launch(args, os.environ):
+        sys.exit(launch(args, argv))
+    run_rank(args)
 
 
 if __name__ == "__main__":

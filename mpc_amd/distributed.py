@@ -22,11 +22,20 @@ def shard_range(batch: int, rank: int, world: int):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _collective_device(t: torch.Tensor, group=None) -> torch.device:
+    """RCCL ("nccl") moves device tensors; every other backend (gloo: CPU tests, and the rehearsal of the multi-rank
+    path on a box with fewer GPUs than ranks) gets host tensors."""
+    if dist.get_backend(group) == "nccl":
+        return t.device
+    return torch.device("cpu")
+
+
 def allreduce_flag(ok, group=None) -> bool:
     """True iff every rank reports True (all-reduce MIN of one int32)."""
     t = ok if torch.is_tensor(ok) else torch.tensor([int(bool(ok))], dtype=torch.int32)
     t = t.to(torch.int32).reshape(1).clone()
     if dist.is_initialized() and dist.get_world_size(group) > 1:
+        t = t.to(_collective_device(t, group))          # a blocking copy when it leaves the device
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
     return bool(t.item())
 
@@ -37,6 +46,16 @@ def allgather_solutions(U_local: torch.Tensor, batch: int, group=None) -> torch.
     its 7 xGMI peers); ragged shards are padded to the largest."""
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return U_local
+    world = dist.get_world_size(group)
+    home = U_local.device
+    cdev = _collective_device(U_local, group)
+    if cdev != home:
+        return allgather_solutions_on(U_local.to(cdev), batch, group).to(home)
+    return allgather_solutions_on(U_local, batch, group)
+
+
+def allgather_solutions_on(U_local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
+    """allgather_solutions on the device the tensor already lives on."""
     world = dist.get_world_size(group)
     sizes = [shard_range(batch, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)

@@ -1,0 +1,68 @@
+"""bench.py --gpus N: the parent starts N fresh ranks before touching the GPU (CPU test of that logic) and the
+partition it measures is BASELINE.json's split of the batch over the ranks."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_defaults_and_launch_decision():
+    b = _bench()
+    a = b.parse_args([])
+    assert (a.gpus, a.steps, a.warmup, a.config, a.scaling) == (1, 50, 5, 3, "strong")
+    assert b.parse_args(["--config", "4"]).steps == 1000          # BASELINE.json configs[3]: 1,000 closed-loop steps
+    a8 = b.parse_args(["--gpus", "8", "--steps", "20", "--warmup", "3"])
+    assert b.needs_launch(a8, {}) is True                           # `python bench.py --gpus 8` typed by hand
+    assert b.needs_launch(a8, {"WORLD_SIZE": "8", "RANK": "0"}) is False   # already a rank of torch.distributed.run
+    assert b.needs_launch(a, {}) is False
+    with pytest.raises(SystemExit):
+        b.parse_args(["--gpus", "0"])
+
+
+def test_launch_command_and_environment():
+    b = _bench()
+    argv = ["--gpus", "4", "--steps", "7"]
+    cmd = b.launch_command(4, argv, 29511, python="py")
+    assert cmd[:3] == ["py", "-m", "torch.distributed.run"]
+    assert "--nproc-per-node=4" in cmd and "--nnodes=1" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1] == "29511"
+    assert cmd[-len(argv) - 1] == os.path.join(ROOT, "bench.py") and cmd[-len(argv):] == argv
+    env = b.launch_env(4, 8, {"PATH": "x"})
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "MPC_BENCH_BACKEND" not in env      # enough GPUs: RCCL
+    assert b.launch_env(2, 1, {})["MPC_BENCH_BACKEND"] == "gloo"                           # one-GPU box: rehearsal
+    assert b.launch_env(2, 1, {"MPC_BENCH_BACKEND": "nccl"})["MPC_BENCH_BACKEND"] == "nccl"
+
+
+def test_launcher_starts_fresh_ranks_and_relays_rank0(tmp_path):
+    """The same launch path with a stand-in rank script: N processes under torch.distributed.run on 127.0.0.1, a gloo
+    all-reduce between them, rank 0's JSON line on the parent's stdout, the children's exit code returned."""
+    b = _bench()
+    script = tmp_path / "rank.py"
+    script.write_text(
+        "import json, os, sys, torch, torch.distributed as dist\n"
+        "dist.init_process_group('gloo')\n"
+        "t = torch.tensor([dist.get_rank() + 1]); dist.all_reduce(t)\n"
+        "if dist.get_rank() == 0: print(json.dumps({'n_gpus': dist.get_world_size(), 'sum': int(t), 'argv': sys.argv[1:]}), flush=True)\n"
+        "dist.destroy_process_group()\n"
+        "sys.exit(3 if '--fail' in sys.argv else 0)\n")
+    import socket
+    for extra, want in (([], 0), (["--fail"], 1)):
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        cmd = b.launch_command(2, ["--steps", "1"] + extra, port)
+        cmd[cmd.index(os.path.join(ROOT, "bench.py"))] = str(script)
+        r = subprocess.run(cmd, env=b.launch_env(2, 0, os.environ), capture_output=True, text=True, timeout=300)
+        assert (r.returncode != 0) == bool(want), r.stderr[-2000:]
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+        assert len(line) == 1
+        out = json.loads(line[0])
+        assert out["n_gpus"] == 2 and out["sum"] == 3 and out["argv"][:2] == ["--steps", "1"]
