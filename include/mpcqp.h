@@ -165,6 +165,21 @@ int  mpcqp_solve_dense(int device_id, int batch, int n, int m, int p, const doub
                        double* x, double* z, double* y, double* obj, int* status, int* iters,
                        double* workspace, int* int_workspace, void* stream);
 
+/* the same with the solver's knobs exposed (what cvxopt.solvers.options carries for the reference:
+ * CollocationBasedPlanner2D.py:16-20 sets maxiters and refinement): */
+typedef struct mpcqp_dense_opts {
+    int    max_steps;   /* cap on active-set steps per QP, status 1 when reached; <= 0: 20 (n+m+p) + 100              */
+    int    prox_iters;  /* cap on proximal-point outer iterations (only singular P needs more than one) (default 30) */
+    int    refine;      /* refinement rounds on the final active set with P itself                       (default 2)  */
+    double sigma_rel;   /* proximal weight relative to max diag of the scaled P                          (default 1e-6) */
+} mpcqp_dense_opts;
+void mpcqp_default_dense_opts(mpcqp_dense_opts* o);
+/* strides as in mpcqp_solve_dense_strided below; opts may be NULL (defaults) */
+int  mpcqp_solve_dense_opts(int device_id, int batch, int n, int m, int p, const double* P, long sP, const double* q,
+                            long sq, const double* G, long sG, const double* h, long sh, const double* A, long sA,
+                            const double* b, long sb, double* x, double* z, double* y, double* obj, int* status,
+                            int* iters, double* workspace, int* int_workspace, const mpcqp_dense_opts* opts, void* stream);
+
 /* mpcqp_solve_dense for callers that cannot allocate.  NO COUNTERPART IN THE REFERENCE: it exists for callers of this
  * boundary that may not call hipMalloc (code under HIP graph capture, tight serving loops, harnesses that forbid
  * allocation) and therefore cannot bring the workspace mpcqp_solve_dense asks for.  The workspace is a static device
@@ -217,6 +232,16 @@ int  mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, c
 int  mpcqp_rows_solve_mpc(int device_id, int batch, int n, int m, int nx, const double* x0, const double* F,
                           const double* f0, const double* E, const double* h0, double* x, double* z, double* obj,
                           int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream);
+
+/* -- pre-solve row hygiene: removeNullConstraints(J, c, threshold) of HelperFuncs.py:41-54 (called at
+ * CollocationBasedPlanner2D.py:338 on the stacked equality rows before they reach solvers.qp) -----------------------
+ * Rows of [J | c] whose coefficients J[i,:] are ALL below `threshold` in magnitude are dropped; the others keep their
+ * order.  J (rows, cols), c (rows): device, row-major.  J_out (rows, cols), c_out (rows): device, capacity of the input,
+ * not aliasing it; the first counts[0] rows are valid afterwards.  counts: device int[2] = {rows kept, rows dropped
+ * although |c| > threshold (the reference prints a warning for each)}.  int_ws: 2 * rows ints.  Asynchronous: read
+ * `counts` after synchronising the stream. */
+int mpcqp_remove_null_rows(int device_id, int rows, int cols, const double* J, const double* c, double threshold,
+                           double* J_out, double* c_out, int* counts, int* int_ws, void* stream);
 
 /* -- scenario model for the closed-loop LTV configuration (BASELINE.json configs[3]; the reference has no counterpart:
  * its scripts keep the model code inline, e.g. CollocationBasedPlanner2D.py:88-347) --------------------------------

@@ -30,6 +30,10 @@ class SolveOpts(C.Structure):
                 ("warm_start", C.c_int), ("stages", C.c_int)]
 
 
+class DenseOpts(C.Structure):
+    _fields_ = [("max_steps", C.c_int), ("prox_iters", C.c_int), ("refine", C.c_int), ("sigma_rel", C.c_double)]
+
+
 class Info(C.Structure):
     _fields_ = [("iters", C.c_void_p), ("status", C.c_void_p), ("obj", C.c_void_p),
                 ("prim_res", C.c_void_p), ("dual_res", C.c_void_p), ("polish_steps", C.c_void_p),
@@ -55,8 +59,12 @@ SYMBOLS = [
     ("mpcqp_recenter", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_get", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),
+    ("mpcqp_remove_null_rows", C.c_int, [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_double] + [C.c_void_p] * 5),
     ("mpcqp_ltv_bicycle", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 13),
     ("mpcqp_solve_dense_strided", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_long] * 6 + [C.c_void_p] * 8 + [C.c_void_p]),
+    ("mpcqp_default_dense_opts", None, [C.POINTER(DenseOpts)]),
+    ("mpcqp_solve_dense_opts", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_long] * 6 + [C.c_void_p] * 8 +
+     [C.POINTER(DenseOpts), C.c_void_p]),
     ("mpcqp_dense_shared_setup", C.c_int, [C.c_int] * 4 + [C.c_void_p] * 6),
     ("mpcqp_dense_shared_solve", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 12),
     ("mpcqp_solve_dense", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 14 + [C.c_void_p]),

@@ -542,10 +542,26 @@ long mpcqp_dense_workspace(int n, int m, int p, long* int_count) {
     return 4L * n * n + mc * n + 2L * n * n + 15L * V;
 }
 
+void mpcqp_default_dense_opts(mpcqp_dense_opts* o) {
+    if (!o) return;
+    o->max_steps = 0; o->prox_iters = 30; o->refine = 2; o->sigma_rel = 1e-6;
+}
+
 int mpcqp_solve_dense_strided(int device_id, int batch, int n, int m, int p, const double* P, long sP, const double* q,
                               long sq, const double* G, long sG, const double* h, long sh, const double* A, long sA,
                               const double* b, long sb, double* x, double* z, double* y, double* obj, int* status,
                               int* iters, double* workspace, int* int_workspace, void* stream) {
+    return mpcqp_solve_dense_opts(device_id, batch, n, m, p, P, sP, q, sq, G, sG, h, sh, A, sA, b, sb, x, z, y, obj, status,
+                                  iters, workspace, int_workspace, nullptr, stream);
+}
+
+int mpcqp_solve_dense_opts(int device_id, int batch, int n, int m, int p, const double* P, long sP, const double* q,
+                           long sq, const double* G, long sG, const double* h, long sh, const double* A, long sA,
+                           const double* b, long sb, double* x, double* z, double* y, double* obj, int* status,
+                           int* iters, double* workspace, int* int_workspace, const mpcqp_dense_opts* opts, void* stream) {
+    mpcqp_dense_opts o;
+    if (opts) o = *opts; else mpcqp_default_dense_opts(&o);
+    if (o.prox_iters < 1 || o.refine < 0 || !(o.sigma_rel > 0.0)) return MPCQP_EINVAL;
     if (batch < 1 || n < 1 || m < 0 || p < 0 || !P || !q || !x || !workspace || !int_workspace) return MPCQP_EINVAL;
     if ((m > 0 && (!G || !h)) || (p > 0 && (!A || !b))) return MPCQP_EINVAL;
     if (sP < 0 || sq < 0 || sG < 0 || sh < 0 || sA < 0 || sb < 0) return MPCQP_EINVAL;
@@ -558,7 +574,8 @@ int mpcqp_solve_dense_strided(int device_id, int batch, int n, int m, int p, con
     d.ws = workspace; d.ws_stride = mpcqp_dense_workspace(n, m, p, &ic);
     d.iws = int_workspace; d.iws_stride = ic;
     d.n = n; d.m = m; d.p = p; d.B = batch;
-    d.max_steps = 20 * (n + m + p) + 100; d.prox_iters = 30; d.refine = 2; d.sigma_rel = 1e-6;
+    d.max_steps = o.max_steps > 0 ? o.max_steps : 20 * (n + m + p) + 100;
+    d.prox_iters = o.prox_iters; d.refine = o.refine; d.sigma_rel = o.sigma_rel;
     // one Hessian and one set of rows for the whole batch: scale and factor them ONCE (a grid of one workgroup into the
     // workspace of QP 0), then every QP solves on that shared set-up with its own q, h, b
     const bool shared = batch > 1 && sP == 0 && (m == 0 || sG == 0) && (p == 0 || sA == 0);

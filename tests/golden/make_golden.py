@@ -94,6 +94,20 @@ def capture(script):
     old = sys.stdout
     sys.stdout = devnull
     try:
+        # record what the script hands to the reference's own removeNullConstraints (HelperFuncs.py:41-54; the
+        # function itself still does the work): the un-pruned rows are a fixture for the device version
+        import importlib
+        hf = importlib.import_module("src.Planner.HelperFuncs")
+        ref_remove = hf.removeNullConstraints
+
+        def recording_remove(J, c, threshold):
+            out = ref_remove(J, c, threshold)
+            store.setdefault("remove_null", []).append(dict(J=np.array(J, dtype=float), c=np.array(c, dtype=float),
+                                                            threshold=float(threshold),
+                                                            J_out=np.array(out[0], dtype=float),
+                                                            c_out=np.array(out[1], dtype=float)))
+            return out
+        hf.removeNullConstraints = recording_remove
         runpy.run_path(os.path.join(REF, "src", "Planner", script), run_name="__main__")
     except _Captured:
         pass
@@ -106,7 +120,7 @@ def capture(script):
     return store
 
 
-def save_ref(name, P, q, G, h, A, b, source, options=None):
+def save_ref(name, P, q, G, h, A, b, source, options=None, extra=None):
     from oracle.qp_oracle import solve_qp
     sol = solve_qp(P, q, G, h, A, b)
     n = q.size
@@ -115,6 +129,7 @@ def save_ref(name, P, q, G, h, A, b, source, options=None):
                A=np.zeros((0, n)) if A is None else A, b=np.zeros(0) if b is None else b.reshape(-1),
                x=sol["x"], z=sol["z"], y=sol["y"], objective=sol["primal objective"],
                kkt=sol["kkt"]["max"], source=np.array(source))
+    out.update(extra or {})
     np.savez_compressed(os.path.join(HERE, f"ref_{name}.npz"), **out)
     print(f"ref_{name}: n={n} m={out['h'].size} p={out['b'].size} status={sol['status']} "
           f"it={sol['iterations']} kkt={sol['kkt']['max']:.2e} obj={sol['primal objective']:.12g}")
@@ -128,7 +143,15 @@ def make_reference_fixtures():
                          ("CollocationBasedPlanner2D.py", "collocation2d_iter0")]:
         st = capture(script)
         P, q, G, h, A, b = st["args"]
-        save_ref(name, P, q, G, h, A, b, f"captured from src/Planner/{script} (first solvers.qp call)")
+        extra = None
+        if st.get("remove_null"):
+            # CollocationBasedPlanner2D.py:338: the stacked equality rows BEFORE the reference's removeNullConstraints, its
+            # threshold, and what the reference's own function returned for them (== A, b of the captured call)
+            rn = st["remove_null"][0]
+            assert np.array_equal(rn["J_out"], A) and np.array_equal(rn["c_out"].reshape(-1), b.reshape(-1))
+            extra = dict(A_unpruned=rn["J"], b_unpruned=rn["c"].reshape(-1), null_threshold=rn["threshold"])
+            print(f"   removeNullConstraints: {rn['J'].shape[0]} rows in, {rn['J_out'].shape[0]} out (reference's own function)")
+        save_ref(name, P, q, G, h, A, b, f"captured from src/Planner/{script} (first solvers.qp call)", extra=extra)
         # the restatement in oracle/reference_qps.py must reproduce the capture bit for bit
         fn = getattr(rq, name + "_qp", None)
         if fn is not None:
@@ -141,6 +164,46 @@ def make_reference_fixtures():
     P, q, G, h, A, b = rq.launch3d_qp()
     save_ref("launch3d", P, q, G, h, A, b,
              "restated from src/Planner/Launch3DPlanner.py:14-199 (script itself fails on NumPy>=1.24 at :33)")
+
+
+def make_remove_null_fixture():
+    """null_rows.npz: inputs and outputs of the REFERENCE's own removeNullConstraints (HelperFuncs.py:41-54,
+    imported from /root/reference) -- on the equality rows CollocationBasedPlanner2D.py:338 hands to it (nothing is
+    removed there) and on the same rows with null rows injected at seeded places (all-zero rows, rows below the
+    threshold, null rows with a non-null right-hand side, which make the reference print a warning)."""
+    import contextlib
+    import importlib
+    import io
+    sys.path.insert(0, REF)
+    try:
+        hf = importlib.import_module("src.Planner.HelperFuncs")
+    finally:
+        sys.path.remove(REF)
+    d = np.load(os.path.join(HERE, "ref_collocation2d_iter0.npz"))
+    A, b, thr = d["A_unpruned"], d["b_unpruned"].reshape(-1, 1), float(d["null_threshold"])
+    rng = np.random.default_rng(7)
+    rows, cols = A.shape
+    extra = 40
+    J = np.vstack([A, np.zeros((extra, cols))]); c = np.vstack([b, np.zeros((extra, 1))])
+    J[rows + 10:rows + 20] = rng.uniform(-1, 1, (10, cols)) * 0.9e-10        # below the threshold everywhere
+    J[rows + 20:rows + 25, 3] = 1.1e-10                                       # one coefficient just above it: kept
+    c[rows + 5:rows + 10] = rng.standard_normal((5, 1))                       # null row, non-null rhs: warned and removed
+    c[rows + 15:rows + 18] = 2.0
+    perm = rng.permutation(rows + extra)
+    J, c = J[perm], c[perm]
+    out = {}
+    for tag, (Ji, ci) in (("plain", (A, b)), ("injected", (J, c))):
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            Jo, co = hf.removeNullConstraints(Ji, ci, thr)
+        text = buf.getvalue()
+        out.update({f"{tag}_J": Ji, f"{tag}_c": ci, f"{tag}_J_out": Jo, f"{tag}_c_out": co,
+                    f"{tag}_warnings": text.count("non zero objective"),
+                    f"{tag}_removed": Ji.shape[0] - Jo.shape[0]})
+        print(f"null_rows[{tag}]: {Ji.shape[0]} rows in, {Jo.shape[0]} out, {out[f'{tag}_warnings']} warnings")
+    np.savez_compressed(os.path.join(HERE, "null_rows.npz"), threshold=thr,
+                        source=np.array("src/Planner/HelperFuncs.py::removeNullConstraints run on the rows of "
+                                        "CollocationBasedPlanner2D.py:338 (plain) and with seeded null rows (injected)"), **out)
 
 
 def make_mpc_fixtures():
@@ -212,7 +275,7 @@ def make_sweep_fixtures():
     """The reference's sequential-QP loops end to end: SE3Planner.py's backward sweeps and
     CollocationBasedPlanner2D.py's SQP iterations, each QP built by the script from the answers to the previous ones.
     Stored: a sample of the QPs (grouped by shape) with their certified optima."""
-    for script, name, every in [("SE3Planner.py", "se3", 8), ("CollocationBasedPlanner2D.py", "collocation2d", 1)]:
+    for script, name, every in [("SE3Planner.py", "se3", 1), ("CollocationBasedPlanner2D.py", "collocation2d", 1)]:
         import time
         t0 = time.time()
         log, total = run_sweep(script, every)
@@ -245,6 +308,8 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["ref", "mpc"]
     if "ref" in which:
         make_reference_fixtures()
+    if "ref" in which or "null" in which:
+        make_remove_null_fixture()
     if "mpc" in which:
         make_mpc_fixtures()
     if "sweep" in which:

@@ -8,6 +8,13 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True)
+def _quiet():
+    from mpc_amd import solvers
+    solvers.options["show_progress"] = False
+    yield
+
 REF = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "ref_*.npz")))
 
 
@@ -122,4 +129,85 @@ def test_reference_sequential_sweeps_replay(name, golden_dir):
             assert np.abs(x[i] - xo).max() <= 1e-6 * max(1.0, np.abs(xo).max()), (gi, i)
             assert abs(obj[i] - oo) <= 1e-8 * max(1.0, abs(oo)), (gi, i)
             checked += 1
-    assert checked >= 8
+    # every call of the script whose own iterate is still finite (SE3Planner.py's rollout diverges after ~95 QPs, SURVEY.md
+    # appendix) and all 10 SQP iterations of CollocationBasedPlanner2D.py
+    assert checked == {"se3": 95, "collocation2d": 10}[name]
+
+
+def test_remove_null_constraints_then_qp(golden_dir, capsys):
+    """HelperFuncs.py:41-54 on the device, against what the reference's own function returned (fixture written by
+    tests/golden/make_golden.py from /root/reference), then the pruned rows through solvers.qp as
+    CollocationBasedPlanner2D.py:338-359 does."""
+    import torch
+    from mpc_amd import solvers
+    from mpc_amd.helper_funcs import removeNullConstraints
+    g = np.load(os.path.join(golden_dir, "null_rows.npz"))
+    thr = float(g["threshold"])
+    for tag in ("plain", "injected"):
+        J, c = g[f"{tag}_J"], g[f"{tag}_c"]
+        capsys.readouterr()
+        Jo, co = removeNullConstraints(J, c, thr)
+        text = capsys.readouterr().out
+        assert isinstance(Jo, np.ndarray) and co.shape == (Jo.shape[0], 1)
+        assert np.array_equal(Jo, g[f"{tag}_J_out"]) and np.array_equal(co, g[f"{tag}_c_out"])          # bit-exact, same order
+        assert text.count("non zero objective") == int(g[f"{tag}_warnings"])
+        assert f"Removing {int(g[f'{tag}_removed'])} constraints" in text
+        Jt, ct = removeNullConstraints(torch.as_tensor(J, device="cuda"), torch.as_tensor(c, device="cuda"), thr)
+        assert Jt.is_cuda and np.array_equal(Jt.cpu().numpy(), Jo) and np.array_equal(ct.cpu().numpy(), co)
+    # the script's step: stack, prune, solve (the injected null rows must not change the answer)
+    d = np.load(os.path.join(golden_dir, "ref_collocation2d_iter0.npz"))
+    Aeq, beq = removeNullConstraints(g["injected_J"], g["injected_c"], thr)
+    solvers.options["show_progress"] = False
+    sol = solvers.qp(solvers.matrix(d["P"], tc="d"), solvers.matrix(d["q"].reshape(-1, 1), tc="d"),
+                     solvers.matrix(d["G"], tc="d"), solvers.matrix(d["h"].reshape(-1, 1), tc="d"),
+                     solvers.matrix(Aeq, tc="d"), solvers.matrix(beq, tc="d"))
+    assert sol["status"] == "optimal"
+    x = np.array(sol["x"]).ravel()
+    assert np.abs(x - d["x"]).max() <= 1e-6 * np.abs(d["x"]).max()
+    assert abs(sol["primal objective"] - float(d["objective"])) <= 1e-8 * abs(float(d["objective"]))
+    z0 = torch.zeros((0, 5), dtype=torch.float64, device="cuda")
+    Je, ce = removeNullConstraints(z0, torch.zeros((0, 1), dtype=torch.float64, device="cuda"), thr)     # empty stack
+    assert tuple(Je.shape) == (0, 5) and tuple(ce.shape) == (0, 1)
+
+
+def test_options_follow_cvxopt_semantics(capsys):
+    """solvers.options as the reference sets them (CollocationBasedPlanner2D.py:16-20, SE3Planner.py:8)."""
+    import warnings
+    from mpc_amd import solvers
+    from oracle import reference_qps as rq
+    P, q, G, h, _, _ = rq.launch3d_qp()
+    saved = dict(solvers.options)
+    try:
+        solvers.options.clear()
+        capsys.readouterr()
+        full = solvers.qp(P, q, G, h)
+        assert "mpc_amd.solvers.qp" in capsys.readouterr().out          # show_progress defaults to True, as in cvxopt
+        assert full["status"] == "optimal" and full["iterations"] > 3
+        assert full["gap"] <= 1e-7 and full["primal infeasibility"] <= 1e-7 and full["dual infeasibility"] <= 1e-7
+        assert abs(full["dual objective"] - full["primal objective"]) <= 1e-8 * abs(full["primal objective"])
+        solvers.options["show_progress"] = False
+        solvers.qp(P, q, G, h)
+        assert capsys.readouterr().out == ""
+        solvers.options["maxiters"] = 3                                  # cap reached: a status, not an exception
+        capped = solvers.qp(P, q, G, h)
+        assert capped["status"] == "unknown" and capped["iterations"] <= 4
+        solvers.options.update(maxiters=500, refinement=1, reltol=1e-4, abstol=1e-5, feastol=1e-5)    # Collocation2D's values
+        assert solvers.qp(P, q, G, h)["status"] == "optimal"
+        solvers.options.clear()
+        solvers.options.update(show_progress=False, feastol=1e-300, abstol=0.0, reltol=0.0)    # a gate nothing can meet
+        strict = solvers.qp(P, q, G, h)
+        assert strict["status"] == "unknown"
+        assert np.array_equal(np.array(strict["x"]), np.array(full["x"]))   # the tolerances gate the status only
+        solvers.options["maxiters"] = 0
+        with pytest.raises(ValueError):
+            solvers.qp(P, q, G, h)
+        solvers.options.clear(); solvers.options["show_progress"] = False
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            solvers.qp(P, q, G, h, initvals={"x": np.zeros(P.shape[0])})
+        assert any("initvals" in str(x.message) for x in w)
+    finally:
+        solvers.options.clear(); solvers.options.update(saved)
+    # cvxopt's nested-list convention: inner lists are columns
+    m = solvers.matrix([[1.0, 2.0], [3.0, 4.0], [5.0, 6.0]])
+    assert m.shape == (2, 3) and m[1, 0] == 2.0 and m.size == (2, 3) and m[2] == 3.0

@@ -187,3 +187,55 @@ def test_sweep_fixtures_are_certified_and_reproducible():
                          A[i] if A.shape[1] else None, b[i] if A.shape[1] else None)
             xo = g["g0_x"][i]
             assert np.abs(s["x"] - xo).max() <= 1e-9 * max(1.0, np.abs(xo).max())
+
+
+def _enumerate_active_sets(P, q, G, h, A, b):
+    """Solver-free: try EVERY subset S of the inequality rows as the active set, solve the equality-constrained QP
+    on it by one linear solve of its KKT system, keep the candidates that are primal feasible with nonnegative
+    multipliers.  For a convex QP each such candidate is a global minimiser (KKT is sufficient)."""
+    import itertools
+    n, m = q.size, h.size
+    pe = 0 if A is None else A.shape[0]
+    hs = max(1.0, np.abs(h).max())
+    found = []
+    for k in range(0, min(m, n - pe) + 1):
+        for S in itertools.combinations(range(m), k):
+            S = list(S)
+            C = np.vstack(([A] if pe else []) + [G[S]]) if (pe or S) else np.zeros((0, n))
+            c = np.concatenate(([b] if pe else []) + [h[S]]) if (pe or S) else np.zeros(0)
+            r = C.shape[0]
+            K = np.zeros((n + r, n + r)); K[:n, :n] = P
+            if r:
+                K[:n, n:] = C.T; K[n:, :n] = C
+            # equilibrate: the reference's launch QP has Hessian entries of 1e-8 beside unit constraint rows
+            s = 1.0 / np.sqrt(np.maximum(np.abs(K).max(1), 1e-300))
+            Ks = K * s[:, None] * s[None, :]
+            if np.linalg.matrix_rank(Ks, tol=1e-11) < n + r:
+                continue                    # dependent rows or a direction of zero curvature: not a vertex candidate
+            sol = s * np.linalg.solve(Ks, s * np.concatenate([-q, c]))
+            x, mult = sol[:n], sol[n:]
+            z = mult[pe:]
+            if (G @ x - h).max() > 1e-9 * hs:
+                continue
+            if z.size and z.min() < -1e-9 * max(1.0, np.abs(z).max()):
+                continue
+            found.append((S, x, 0.5 * x @ P @ x + q @ x))
+    return found
+
+
+@pytest.mark.parametrize("name", ["launch1d", "collocation1d"])
+def test_brute_force_active_set_enumeration_pins_the_golden_optimum(name, golden_dir):
+    """Third, solver-free pin for the two reference QPs small enough to enumerate:
+    LaunchPlannerQPFormulation.py:173 (2 variables, 8 rows: 37 candidate sets) and CollocationBasedPlanner.py:59
+    (8 variables, 10 rows, 4 equalities: 386 candidate sets).  Every KKT point found by enumeration must coincide with
+    the stored golden optimum in x and in objective."""
+    (P, q, G, h, A, b), d = _load(os.path.join(golden_dir, f"ref_{name}.npz"))
+    found = _enumerate_active_sets(P, q, G, h, A if A.size else None, b if b.size else None)
+    assert found, "enumeration found no KKT point"
+    xg, og = d["x"], float(d["objective"])
+    for S, x, obj in found:
+        assert abs(obj - og) <= 1e-9 * max(abs(og), 1e-300), (S, obj, og)
+        assert np.abs(x - xg).max() <= 1e-7 * max(np.abs(xg).max(), 1e-300), S
+    # the golden active set (rows with a positive multiplier) is among the enumerated ones
+    act = sorted(np.nonzero(d["z"] > 1e-9 * max(1.0, np.abs(d["z"]).max()))[0].tolist())
+    assert any(sorted(S) == act for S, _, _ in found) or any(set(act) <= set(S) for S, _, _ in found)
