@@ -63,13 +63,14 @@ typedef struct mpcqp_dims {
 typedef struct mpcqp_factor_opts {
     double rho;        /* ADMM penalty in Jacobi-scaled variables; <= 0: pick from the spectrum */
     int    no_sync;    /* 1: do not synchronise the stream to report rho / a failed factorisation to the host
-                          (needs rho > 0 or n_models > 1); failures then show up as per-instance status     */
+                          (needs rho > 0 or n_models > 1); failures then show up as per-instance status
+                          MPCQP_MAX_ITER of the following solves (shared model: every instance)              */
     int    keep_state; /* 1: the kept (z, w) stays valid across this re-factorisation (closed loop, warm start) */
 } mpcqp_factor_opts;
 
 typedef struct mpcqp_solve_opts {
     int    max_iter;      /* ADMM iterations before the active-set stage (default 0: the active-set kernels alone are
-                             fastest when few bounds bind -- 0.57 ms vs 0.78 ms with 5 iterations at BASELINE configs[2];
+                             fastest when few bounds bind -- measured table in DESIGN.md section 2 item 5;
                              a few iterations pay off when large active sets must be guessed)                */
     int    min_iter;      /* iterations before the first convergence check        (default 5)   */
     int    check_every;   /* residual / active-set check period                   (default 5)   */
@@ -146,7 +147,10 @@ int mpcqp_recenter(mpcqp_handle h, void* stream);
 /* -- introspection (device -> caller's device buffers; for tests and parity reports) --- */
 /* which: 0 H (n,n)  1 F (n,nx)  2 f0 (n)  3 Gamma (N nx, n)  4 Phi (N nx, nx)
  *        5 Hs (n,n) 6 M=(Hs+rho I)^-1 (n,n)  7 Hi=Hs^-1 (n,n)  8 d (n)  9 rho (1)
- *        10 z (batch,n) scaled  11 w (batch,n) scaled                                    */
+ *        10 z (batch,n) scaled  11 w (batch,n) scaled
+ *        12 diagnostics of the last solve (96 values): [0] instances handed to the second active-set pass (routed by the
+ *           cold-start ordering + overflow of the first), [1] handed on to the 64-row pass, [2] instances the first pass
+ *           took, [3] handed to the any-size pass, [16..48) histogram of the cold-start keys                          */
 int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, void* stream);
 
 /* -- dense QP: the reference's literal call  cvxopt.solvers.qp(P, q, G, h[, A, b]) ---------------------

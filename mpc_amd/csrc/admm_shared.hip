@@ -30,7 +30,7 @@ struct AdmmParams {
     int* conv;              // [B] 1 if the eps criterion was met
     double* prim;           // [B]
     double* dual;           // [B]
-    int B, nx, SX;
+    int B, nx, SX, dev;
     int k_in_lds;           // 1: Kbfrag, Kufrag are staged behind M in LDS
     int max_iter, min_iter, check_every, warm, stop_on_stable;
     double eps_abs, eps_rel, alpha, rho;
@@ -335,13 +335,8 @@ int launch_one(const AdmmParams& p, hipStream_t st) {
     AdmmParams q = p;
     q.k_in_lds = (lds + klds <= 160 * 1024) ? 1 : 0;
     if (q.k_in_lds) lds += klds;
-    static size_t attr_set = 0;
-    if (attr_set < lds) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&admm_shared_box_kernel<NT, S>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = lds;
-    }
+    const hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&admm_shared_box_kernel<NT, S>), lds);
+    if (e != hipSuccess) return (int)e;
     const int nblk16 = ceil_div(p.B, 16);
     const int grid = ceil_div(nblk16, 4);
     hipLaunchKernelGGL((admm_shared_box_kernel<NT, S>), dim3(grid), dim3(256), lds, st, q);
@@ -363,7 +358,7 @@ int launch_admm_shared_box(mpcqp_handle h, const double* x0, int B, const mpcqp_
     p.Mfrag = h->Mfrag; p.Kbfrag = h->Kbfrag; p.Kufrag = h->Kufrag;
     p.lbs = h->lbs; p.ubs = h->ubs; p.x0 = x0;
     p.b0ws = h->b0ws; p.z = h->z; p.w = h->w; p.iters = h->it_ws; p.conv = h->it_ws + 2 * (size_t)h->Bcap; p.prim = h->rp_ws; p.dual = h->rd_ws;
-    p.B = B; p.nx = h->dims.nx; p.SX = h->SX;
+    p.B = B; p.nx = h->dims.nx; p.SX = h->SX; p.dev = h->dev;
     p.max_iter = o.max_iter; p.min_iter = o.min_iter; p.check_every = o.check_every > 0 ? o.check_every : 1;
     p.warm = (o.warm_start && h->has_state) ? 1 : 0;
     p.stop_on_stable = o.polish ? 1 : 0;

@@ -3,6 +3,21 @@
 #include <cstring>
 #include <new>
 
+#include <map>
+#include <mutex>
+#include <utility>
+
+hipError_t ensure_dyn_lds(int device, const void* kernel, size_t bytes) {
+    static std::mutex mu;
+    static std::map<std::pair<int, const void*>, size_t> set_to;
+    std::lock_guard<std::mutex> lock(mu);
+    size_t& have = set_to[{device, kernel}];
+    if (have >= bytes && have > 0) return hipSuccess;
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) have = bytes;
+    return e;
+}
+
 namespace {
 
 std::string g_create_err;
@@ -32,7 +47,6 @@ int ensure_batch(mpcqp_handle h, int B) {
 }
 
 __global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int nu) {
-    // one thread per (block of 16 instances, column); walk the rows forward by one stage
     // one 64-lane wave per instance; rows move forward by one stage (nu rows), the last stage repeats
     const int inst = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (inst >= nblk) return;
@@ -51,6 +65,11 @@ __global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int 
         const int r = lane + 64 * q;
         if (r < n) { zb[r] = zv[q]; wb[r] = wv[q]; }
     }
+}
+
+__global__ void ints_to_doubles_kernel(const int* in, double* out, int count) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = (double)in[i];
 }
 
 __global__ void unblock_kernel(const double* zb, double* out, int B, int NP, int n) {
@@ -263,6 +282,15 @@ int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, v
             HIPCHK(h, hipSetDevice(h->dev));
             hipLaunchKernelGGL(unblock_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0,
                                static_cast<hipStream_t>(stream), which == 10 ? h->z : h->w, out, h->Blast, h->NP, h->n);
+            HIPCHK(h, hipGetLastError());
+            return MPCQP_OK;
+        }
+        case 12: {
+            if (!h->has_state) { h->err = "get: no solution state yet"; return MPCQP_ESTATE; }
+            if (out_len < 96) { h->err = "get: output buffer too small"; return MPCQP_EINVAL; }
+            HIPCHK(h, hipSetDevice(h->dev));
+            hipLaunchKernelGGL(ints_to_doubles_kernel, dim3(1), dim3(96), 0, static_cast<hipStream_t>(stream),
+                               h->it_ws + 5 * (size_t)h->Bcap, out, 96);
             HIPCHK(h, hipGetLastError());
             return MPCQP_OK;
         }

@@ -245,8 +245,7 @@ int launch_assemble(mpcqp_handle h, hipStream_t st) {
     if (a.ab_in_lds) lds += ab;
     lds = std::max<size_t>(lds, 256 * sizeof(double));                     // the f0 partial sums reuse the front of it
     if (lds > 160 * 1024) { h->err = "assemble: nx too large for the LDS buffers"; return MPCQP_ENOTIMPL; }
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&assemble_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&assemble_kernel), lds);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return MPCQP_EHIP; }
     hipLaunchKernelGGL(assemble_kernel, dim3(h->dims.n_models), dim3(256), lds, st, a);
     e = hipGetLastError();

@@ -65,6 +65,10 @@ struct mpcqp_handle_s {
         }                                                                            \
     } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-device property of a kernel: set it once per (device, kernel) and
+// whenever a launch needs more than was set, not on every launch of the timed path (api.hip; mutex-guarded)
+hipError_t ensure_dyn_lds(int device, const void* kernel, size_t bytes);
+
 // ---- launchers implemented in the kernel translation units ----------------------
 int launch_assemble(mpcqp_handle h, hipStream_t st);
 int launch_factor(mpcqp_handle h, double rho, hipStream_t st);

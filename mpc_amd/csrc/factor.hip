@@ -607,14 +607,14 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st) {
     hipError_t e = hipMemsetAsync(h->rho_dev, 0, 4 * sizeof(double), st);
     if (e == hipSuccess) e = hipMemsetAsync(h->flag_dev, 0, sizeof(int), st);
     if (e == hipSuccess && f.use_lds)
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(&factor_batch_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&factor_batch_kernel), lds);
     if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
     if (h->n <= 64) {       // one wave per model
         const int nb = ceil_div(h->n, 16);
         const size_t npd = 16 * (size_t)nb;
         const size_t wl = (npd * (npd + 1) + h->n + std::max<size_t>((size_t)h->n * (h->dims.nx + 1), 2 * (size_t)h->n)) * sizeof(double);
         auto kern = nb == 1 ? &factor_wave_kernel<1> : nb == 2 ? &factor_wave_kernel<2> : nb == 3 ? &factor_wave_kernel<3> : &factor_wave_kernel<4>;
-        e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)wl);
+        e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(kern), wl);
         if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
         hipLaunchKernelGGL(kern, dim3(h->dims.n_models), dim3(64), wl, st, f);
     } else

@@ -12,11 +12,11 @@ struct PolParams {
     int* need_big;                 // [B]: 1 if the fast pass overflowed KMAX
     double* U;                     // [B][n]
     mpcqp_info info;
-    int B, n, nx, NP;
+    int B, n, nx, NP, dev;
     int polish, refine, max_steps, pass;   // pass 0: fast, 1: big
     double rho;
     long st_nn, st_k, st_np, st_n;  // one model per instance: element strides of (Hs,Hi), (FsT,KuT), (lbs,ubs), d; 0 = shared
-    const int* mflag;              // per-model factorisation failure flags (nullptr: shared model)
+    const int* mflag;              // factorisation failure flags: one per model (st_nn != 0) or the shared model's single flag
     int cold; int admm_ran; const double* Cq;                      // 1: no (z, w) to start from -- begin with the empty active set
     const int *qin, *qin_count;    // instance queue to take the work from (nullptr: instances 0..B-1)
     int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)

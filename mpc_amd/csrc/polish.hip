@@ -214,7 +214,10 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
 
     int status = MPCQP_SOLVED_INACCURATE;
     int steps = 0;
-    bool overflow = false, fail = (p.mflag != nullptr) && p.mflag[inst] != 0;
+    // a failed factorisation (this instance's own model, or the one shared model: the flag a factor call with no_sync
+    // leaves on the device) is reported as status MPCQP_MAX_ITER, never as a solution
+    const bool mfail = (p.mflag != nullptr) && p.mflag[p.st_nn ? inst : 0] != 0;
+    bool overflow = false, fail = mfail;
 
     if (p.polish && !fail) {
         // ---- warm phase: solve on the guessed set, release wrong-signed multipliers -------------
@@ -444,7 +447,7 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
             const int j = lane + 64 * q;
             if (j < n) { x[q] = fmin(fmax(zb[j], lo[q]), hi[q]); lam[q] = p.rho * wb[j]; }
         }
-        status = (p.admm_ran && p.cv_ws[inst]) ? MPCQP_SOLVED_INACCURATE : MPCQP_MAX_ITER;
+        status = (p.admm_ran && p.cv_ws[inst] && !mfail) ? MPCQP_SOLVED_INACCURATE : MPCQP_MAX_ITER;
     }
 
     // ---- objective 1/2 x'Hs x + qs'x ---------------------------------------------------------------
@@ -515,8 +518,7 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
 template <int KMAX, int WAVES>
 int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
     const size_t lds = sizeof(WaveLds<KMAX>) * WAVES;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_box_kernel<KMAX, WAVES>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_box_kernel<KMAX, WAVES>), lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((polish_box_kernel<KMAX, WAVES>), dim3(blocks > 0 ? blocks : ceil_div(p.B, WAVES)), dim3(64 * WAVES), lds, st, p);
     return (int)hipGetLastError();
@@ -533,7 +535,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     p.cv_ws = h->it_ws + 2 * (size_t)h->Bcap;
     p.U = U;
     if (info) p.info = *info; else p.info = mpcqp_info{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    p.B = B; p.n = h->n; p.nx = h->dims.nx; p.NP = h->NP;
+    p.B = B; p.n = h->n; p.nx = h->dims.nx; p.NP = h->NP; p.dev = h->dev;
     p.polish = o.polish;
     // refine < 0: automatic -- one step with Hs itself only if the explicit inverse is not accurate enough
     p.refine = o.polish_refine >= 0 ? o.polish_refine : (h->inv_resid > 1e-9 ? 1 : 0); p.max_steps = o.polish_max_steps > 0 ? o.polish_max_steps : 4 * h->n + 16;
@@ -550,12 +552,12 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     p.st_nn = per_model ? (long)h->n * h->n : 0; p.st_k = per_model ? (long)h->NP * (h->dims.nx + 1) : 0;
     p.st_np = per_model ? h->NP : 0; p.st_n = per_model ? h->n : 0;
     // cold: no ADMM iterate to start from (one model per instance, or max_iter = 0 without a kept state): the kernels
-    // start from the bounds the unconstrained minimiser violates
+    // start from the empty active set
     const bool no_admm = o.max_iter == 0 && o.polish && (o.stages & 1);     // api.hip skipped the ADMM launch
     p.cold = ((per_model || no_admm) && !(o.warm_start && h->has_state)) ? 1 : 0;
     p.admm_ran = (!per_model && !no_admm) ? 1 : 0;      // iters / residuals / converged flags are the ADMM kernel's
     p.Cq = per_model ? nullptr : h->Cq;
-    p.mflag = per_model ? h->mflag : nullptr;
+    p.mflag = per_model ? h->mflag : h->flag_dev;
     p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
     // int workspace beyond [iters | need_big | converged]: two instance queues and their counters

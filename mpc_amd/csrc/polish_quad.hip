@@ -1,16 +1,16 @@
-// Polish, fast path: the same dual active-set method as polish.hip (Goldfarb-Idnani on the Schur
-// complement S = Hi[A,A] of the shared inverse Hi = Hs^-1, warm-started from the ADMM iterate), laid
-// out for what the workload looks like.  On condensed MPC QPs the optimal active set is small
-// (config 3, measured: mean 7.4 of 120 bounds, 97.7 % of instances <= 16, 99.98 % <= 24), so the
-// per-instance arithmetic is a few thousand flops and the one-wave-per-instance kernel spends its
-// time issuing 64-wide instructions for 7-element vectors and walking Cholesky columns one by one.
+// Active-set stage, fast path ("polish" in the names: it began as the step that made an ADMM iterate exact and is now the
+// whole default solve): the same dual active-set method as polish.hip (Goldfarb-Idnani on the Schur complement
+// S = Hi[A,A] of the shared inverse Hi = Hs^-1), started from the EMPTY set (cold, the default) or from the guess a kept /
+// ADMM iterate (z, w) provides (warm), laid out for what the workload looks like.  On condensed MPC QPs the optimal active
+// set is small (config 3, measured: mean 7.4 of 120 bounds, 97.7 % of instances <= 16, 99.98 % <= 24), so the
+// per-instance arithmetic is a few thousand flops and a one-wave-per-instance kernel would spend its time issuing 64-wide
+// instructions for 7-element vectors and walking Cholesky columns one by one.
 //
-// Mapping: EIGHT lanes per instance (half a DPP row), 64 instances per 512-thread workgroup, two
-// waves per SIMD.
-//   * Hi (n x n, odd row stride) is staged ONCE per workgroup into LDS and serves all 64 instances;
+// Mapping: G = 8 (first pass) or 32 (second pass) lanes per instance, 512-thread workgroups.
+//   * Hi (n x n, odd row stride) is staged ONCE per workgroup into LDS and serves all its instances;
 //     it is symmetric, so "column p restricted to my rows" is a contiguous row read.
-//   * lane g of the group owns the row pairs (16j+2g, 16j+2g+1), j < RP, of x in registers.
-//   * Instead of a Cholesky factor the group keeps W = S^-1 itself (k <= KMAX), rows 8i+g in lane g,
+//   * lane g of the group owns the row pairs (2 G j + 2 g, + 1), j < RP, of x in registers.
+//   * Instead of a Cholesky factor the group keeps W = S^-1 itself (k <= KMAX), rows G i + g in lane g,
 //     embedded in a KMAX x KMAX matrix whose unused rows/columns are zero.  Every update is then a
 //     matrix-vector product or a rank-one update with compile-time register indices and no
 //     column-by-column dependency chain:
@@ -19,10 +19,10 @@
 //     (block-inverse / Sherman-Morrison forms of what polish.hip does with its factor; S is a
 //     principal submatrix of Hi, cond <= cond(Hs), and there are at most a few dozen updates).
 //     Vectors a whole group needs (r, W[j,:], the row list) are exchanged through a per-instance LDS
-//     scratch; scalars are reduced with DPP (quad_perm + row_half_mirror).
-//   * the 8 instances of a wave advance in lock-step (one add/drop per round, predicated).
-// Instances whose active set outgrows KMAX (or that hit a numerical guard) are flagged in need_big and
-// redone from the untouched ADMM iterate by the wave-per-instance kernel (polish.hip).
+//     scratch; scalars are reduced with DPP (quad_perm, row_half_mirror, row_ror) and one ds_bpermute for G = 32.
+//   * the instances of a wave advance in lock-step (one add/drop per round, predicated).
+// Instances whose active set outgrows KMAX (or that hit a numerical guard) are queued on the device for the next,
+// larger pass; the last resort is the wave-per-instance kernel (polish.hip).
 //
 // Reference counterpart: as polish.hip -- the accuracy of soln['x'] (LaunchPlannerQPFormulation.py:174).
 #include "polish.h"
@@ -285,6 +285,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     int khi = 0;                        // 1 + highest slot ever occupied
     bool over = false, fail = false;
     int steps = 0, why = 0;
+    if (p.mflag && p.mflag[0]) { fail = true; why = 8; }      // the shared factorisation failed: the wave kernel reports it
 
     // r = W h with h_c = Hi[p][row_c]; also h at my own slots
     auto sinv_h = [&](int po, int lim, double (&r)[NS], double (&hown)[NS]) {
@@ -746,8 +747,7 @@ int launch_oct(const PolParams& p, int ninst, hipStream_t st) {
     const size_t xch = (size_t)IPW * KMAX * 20;
     const size_t lds = ((size_t)p.n * LD + 3 * NQ) * 8 + (stage > xch ? stage : xch);
     if (lds > 160 * 1024) return -1;
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS>), lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
     return (int)hipGetLastError();
@@ -769,10 +769,6 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 
 }  // namespace
 
-// Fast polish: pass A takes the whole batch with KMAX = 16 (two waves per SIMD); what outgrows it is queued
-// on the device and retried by pass B with KMAX = 32 and sixteen lanes per instance on at most
-// `second_cap` queue slots; what is left after that is queued in p2.qout for the wave-per-instance kernel.
-// returns 0 on launch, -1 if the shape does not fit this path, a hipError_t (> 0) otherwise
 // ---- cold start: order the instances by expected work ---------------------------------------------------------------------
 // The lanes of a wave walk their 8 (16) instances in lock-step, so a wave takes as long as its slowest instance.  Without
 // an ADMM iterate the number of bounds the unconstrained minimiser violates predicts the number of active-set steps:
@@ -859,6 +855,10 @@ __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, cons
     if (inst < B) (key >= route ? q1 : order)[base[key] + local] = inst;
 }
 
+// The two fast passes: pass A (8 lanes per instance, KMAX = 16) takes the whole batch -- in cold-start order, minus the
+// instances the ordering routes straight to pass B; what outgrows it is queued on the device (q1) and taken by pass B
+// (32 lanes per instance, KMAX = 32); what is left after that is queued in q2 for the wave-per-instance kernel.
+// Returns 0 on launch, -1 if the shape does not fit this path, a hipError_t (> 0) otherwise.
 int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, int stop_after) {
     if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
     hipError_t e = hipMemsetAsync(counters, 0, 96 * sizeof(int), st);       // queue counters, buckets, cursors
@@ -867,14 +867,13 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
     const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
     const size_t kl = ((size_t)kp * nq + 2 * nq + 64 * (size_t)kp) * sizeof(double);
-    if (p.cold && p.B >= 4096 && kl <= 64 * 1024 && !getenv("MPCQP_NO_ORDER")) {
+    if (p.cold && p.B >= 4096 && kl <= 64 * 1024) {
         // keys in q2 (written again only by the second pass), buckets / cursors / count in the counter block,
         // the order in the last slot of the int workspace
         int* keys = q2; int* order = counters + 96;
         int* bins = counters + 16; int* cursors = bins + NBIN; int* count = counters + 2;
         hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins);
-        int route = std::min(NBIN, 2 * 16 / 3);                    // first-pass capacity 16 rows; swept 8..14: 10 is best
-        if (const char* ev = getenv("MPCQP_ROUTE")) route = std::max(1, std::min(NBIN, atoi(ev)));   // tuning experiments
+        const int route = std::min(NBIN, 2 * 16 / 3);              // first-pass capacity 16 rows; swept 8..14: 10 is best
         hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, bins, cursors, order, q1, count,
                            counters, p.B, route);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;

@@ -624,8 +624,7 @@ static int rows_solve_impl(int device_id, int batch, int n, int m, const double*
     const size_t lds1 = lds_of(KL1), lds2 = lds_of(KL2);
     if (lds1 > 160 * 1024) return MPCQP_ENOTIMPL;
     const bool second = KL2 > KL1 && lds2 <= 160 * 1024;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rows_qp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)(second ? lds2 : lds1)) != hipSuccess) return MPCQP_EHIP;
+    if (ensure_dyn_lds(device_id, reinterpret_cast<const void*>(&rows_qp_kernel), second ? lds2 : lds1) != hipSuccess) return MPCQP_EHIP;
     r.KL = KL1; r.pass = 1;
     hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds1, st, r);
     if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;

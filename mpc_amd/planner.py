@@ -412,12 +412,12 @@ class Planner:
 
     # ---- introspection -------------------------------------------------------------------
     _GET = {"H": 0, "F": 1, "f0": 2, "Gamma": 3, "Phi": 4, "Hs": 5, "M": 6, "Hi": 7, "d": 8, "rho": 9,
-            "z": 10, "w": 11}
+            "z": 10, "w": 11, "queues": 12}
 
     def get(self, name, batch=None, model=0):
         n, p, nx = self.n, self.N * self.nx, self.nx
         shapes = {"H": (n, n), "F": (n, nx), "f0": (n,), "Gamma": (p, n), "Phi": (p, nx), "Hs": (n, n),
-                  "M": (n, n), "Hi": (n, n), "d": (n,), "rho": (3,)}
+                  "M": (n, n), "Hi": (n, n), "d": (n,), "rho": (3,), "queues": (96,)}
         if name in ("z", "w"):
             if batch is None:
                 raise ValueError("get('z'|'w') needs batch=")

@@ -194,6 +194,26 @@ def test_error_conventions():
         pm.solve(np.zeros((3, 2)))
 
 
+def test_no_sync_factor_failure_is_reported_as_status():
+    """mpcqp_factor with no_sync = 1 cannot tell the host that H is indefinite; the shared model's failure flag stays on
+    the device and every instance of the following solve reports MPCQP_MAX_ITER instead of a made-up solution."""
+    from mpc_amd import _lib
+    from mpc_amd.planner import Planner
+    for max_iter in (0, 3):
+        pl = Planner(2, 1, 5)
+        pl.no_sync = True
+        pl.set_model(np.eye(2), np.ones((2, 1)))
+        pl.set_cost(-np.eye(2), -np.eye(1))             # not PD
+        pl.set_constraints([-1.0], [1.0])
+        pl.solve(np.ones((70, 2)), rho=0.1, max_iter=max_iter)   # rho given + no_sync: the factor call does not synchronise
+        st = pl.info.status.cpu().numpy()
+        assert (st == _lib.MAX_ITER).all(), st
+        # the same handle with a definite cost afterwards: the flag is cleared by the next factorisation
+        pl.set_cost(np.eye(2), np.eye(1))
+        pl.solve(np.ones((70, 2)), rho=0.1, max_iter=max_iter)
+        assert (pl.info.status.cpu().numpy() == _lib.SOLVED).all()
+
+
 def test_horizon_beyond_128_inputs_goes_to_the_dense_kernel():
     from mpc_amd.planner import Planner
     from oracle import mpc_oracle as mo
