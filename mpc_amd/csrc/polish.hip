@@ -543,8 +543,8 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     p.prof = nullptr;
 #ifdef POLISH_PROF
     static unsigned long long* profbuf = nullptr;
-    if (!profbuf) { (void)hipMalloc(&profbuf, 16 * 8); }
-    (void)hipMemsetAsync(profbuf, 0, 16 * 8, st);
+    if (!profbuf) { (void)hipMalloc(&profbuf, 32 * 8); }
+    (void)hipMemsetAsync(profbuf, 0, 32 * 8, st);
     p.prof = profbuf;
 #endif
     p.pass = 0;
@@ -572,14 +572,19 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     if (rc == 0 && (o.stages & 12)) return MPCQP_OK;
 #ifdef POLISH_PROF
     if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {
-        unsigned long long pr[16]; int cn[2];
+        unsigned long long pr[32]; int cn[4];
         (void)hipStreamSynchronize(st);
         (void)hipMemcpy(pr, profbuf, sizeof(pr), hipMemcpyDeviceToHost);
         (void)hipMemcpy(cn, counters, sizeof(cn), hipMemcpyDeviceToHost);
-        const double nw = (double)ceil_div(B, 64) * 8;
-        fprintf(stderr, "[polish prof] queued after pass A %d, after pass B %d of %d; per wave cycles (A+B): stage %.0f xu %.0f warm-build %.0f warm-lam %.0f "
-                "xeval %.0f main %.0f out %.0f | build iters %.1f inner iters %.1f\n", cn[0], cn[1], B,
-                pr[0] / nw, pr[1] / nw, pr[2] / nw, pr[3] / nw, pr[4] / nw, pr[5] / nw, pr[6] / nw, pr[7] / nw, pr[8] / nw);
+        const char* nm[16] = {"stage", "xu", "warm-build", "warm-lam", "xeval", "refine", "out", "#build", "#inner", "scan", "direction",
+                              "x-update", "append", "drop", "#drops", ""};
+        for (int k = 0; k < 2; ++k) {
+            const double nw = k == 0 ? (double)ceil_div(cn[2] > 0 ? cn[2] : B, 8) : (double)ceil_div(cn[0], 2);
+            fprintf(stderr, "[polish prof] pass %c: %d instances, %.0f waves; per wave (100 MHz ticks):", k ? 'B' : 'A', k ? cn[0] : (cn[2] > 0 ? cn[2] : B), nw);
+            for (int i = 0; i < 15; ++i) fprintf(stderr, " %s %.1f", nm[i], pr[16 * k + i] / nw);
+            fprintf(stderr, " | longest wave %llu ticks", pr[16 * k + 15]);
+            fprintf(stderr, "\n");
+        }
     }
 #endif
     if (rc == 0) {

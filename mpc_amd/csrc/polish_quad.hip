@@ -29,6 +29,11 @@
 #include <cstdlib>
 #include <algorithm>
 
+#ifndef OCT_CH32
+#define OCT_CH32 4
+#define OCT_XCH32 2
+#endif
+
 namespace {
 
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;     // quad_perm [1,0,3,2], [2,3,0,1]
@@ -106,8 +111,9 @@ __device__ __forceinline__ double frcp(double x) {
 }
 
 #ifdef POLISH_PROF
-#define PROF_MARK(i) do { const long long t_ = clock64(); if (lane == 0 && p.prof) atomicAdd(p.prof + (i), (unsigned long long)(t_ - tprof)); tprof = t_; } while (0)
-#define PROF_CNT(i) do { if (lane == 0 && p.prof) atomicAdd(p.prof + (i), 1ull); } while (0)
+// wave-uniform accumulators (scalar registers), one atomic per counter at the end of the kernel
+#define PROF_MARK(i) do { const long long t_ = clock64(); pacc[i] += (unsigned long long)(t_ - tprof); tprof = t_; } while (0)
+#define PROF_CNT(i) do { pacc[i] += 1ull; } while (0)
 #else
 #define PROF_MARK(i)
 #define PROF_CNT(i)
@@ -120,47 +126,48 @@ __device__ __forceinline__ double frcp(double x) {
 #define ROW_OWNER(r) ((((r) >> 1) & (G - 1)) == g)
 #define ROW_BIT(r) ((((r) / (2 * G)) << 1) | ((r) & 1))
 
-template <int G, int RP, int KMAX, int THREADS>
-__global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int IPW = THREADS / G;     // instances per workgroup
-    constexpr int NS = KMAX / G;         // list slots per lane: position a = G i + g
-    constexpr int RPL = 2 * RP;          // rows per lane
-    constexpr int NQ = 2 * G * RP;       // rows incl. padding
-    constexpr int LD = NQ | 1;           // odd row stride: distinct rows of Hi start in distinct banks
-    constexpr int CH = 4, XCH = 2;       // list columns handled per uniform-exit test (loads of a chunk are in flight together)
-    const int n = p.n, nx = p.nx;
-    const int tid = threadIdx.x, g = tid & (G - 1), li = tid / G;
-    [[maybe_unused]] const int lane = tid & 63;
-    double* sHi = reinterpret_cast<double*>(smem);   // [n][LD], columns >= n are zero
-    double* sLb = sHi + (size_t)n * LD;              // [NQ] padded rows: -1e300
-    double* sUb = sLb + NQ;                          // [NQ] padded rows: +1e300
-    double* sD = sUb + NQ;                           // [NQ] Jacobi scaling
-    double* sStage = sD + NQ;                        // prologue: KuT, FsT [(nx+1)][NQ], x0 [64][nx]; then the exchange scratch
-    double* sKu = sStage;
-    double* sFs = sKu + (size_t)(nx + 1) * NQ;
-    double* sX0 = sFs + (size_t)(nx + 1) * NQ;
-    double* myR = sStage + (size_t)li * KMAX;                                  // [IPW][KMAX] vector exchange 1
-    double* myV = sStage + (size_t)(IPW + li) * KMAX;                          // [IPW][KMAX] vector exchange 2
-    int* myA = reinterpret_cast<int*>(sStage + (size_t)2 * IPW * KMAX) + li * KMAX; // [IPW][KMAX] row of each list slot
+#define OCT_LAYOUT \
+    extern __shared__ __attribute__((aligned(16))) char smem[]; \
+    constexpr int IPW = THREADS / G; \
+    constexpr int NS = KMAX / G; \
+    constexpr int RPL = 2 * RP; \
+    constexpr int NQ = 2 * G * RP; \
+    constexpr int LD = NQ | 1; \
+    constexpr int CH = (G >= 32) ? OCT_CH32 : 4, XCH = (G >= 32) ? OCT_XCH32 : 2; \
+    const int n = p.n, nx = p.nx; \
+    const int tid = threadIdx.x, g = tid & (G - 1), li = tid / G; \
+    [[maybe_unused]] const int lane = tid & 63; \
+    double* sHi = reinterpret_cast<double*>(smem); \
+    double* sLb = sHi + (size_t)n * LD; \
+    double* sUb = sLb + NQ; \
+    double* sD = sUb + NQ; \
+    double2* sBT = reinterpret_cast<double2*>(sD + NQ); \
+    double* sKu = sD + 3 * NQ; \
+    double* sStage = sKu + (size_t)(nx + 1) * NQ; \
+    double* sX0 = sStage; \
+    double* myR = sStage + (size_t)li * KMAX; \
+    double* myV = sStage + (size_t)(IPW + li) * KMAX; \
+    int* myA = reinterpret_cast<int*>(sStage + (size_t)2 * IPW * KMAX) + li * KMAX; \
 
+
+// one block of IPW instances: the whole active-set solve
+template <int G, int RP, int KMAX, int THREADS, bool COLD>
+__device__ __forceinline__ void oct_block(const PolParams& p, const int blk, const int total, unsigned long long* pacc_out) {
+    OCT_LAYOUT
 #ifdef POLISH_PROF
+    unsigned long long pacc[16] = {};
     long long tprof = clock64();
 #endif
-    // instances: a contiguous block of the batch, or (second chance pass) entries of a device-side queue
-    const int total = p.qin ? *p.qin_count : p.B;
-    const int slot0 = blockIdx.x * IPW;
-    if (slot0 >= total) return;
+    const int slot0 = blk * IPW;
     const bool valid = slot0 + li < total;
     const int inst = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
-
     // the ADMM iterate (z, w) of my rows: issued first so that the HBM latency hides behind the staging below
     double zz[RPL], ww[RPL];
 #pragma unroll
     for (int j = 0; j < RPL; ++j) { zz[j] = 0.0; ww[j] = 0.0; }
     double* zb = p.z + (size_t)inst * p.NP;
     double* wb = p.w + (size_t)inst * p.NP;
-    if (valid && !p.cold) {
+    if (!COLD && valid) {
         if (!(n & 1)) {     // pairs never straddle n: 16-byte loads
 #pragma unroll
             for (int jj = 0; jj < RP; ++jj) {
@@ -179,36 +186,8 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         }
     }
 
-    // ---- stage the shared data --------------------------------------------------------------
-    {   // Hi -> LDS, six rows in flight per thread (n <= 128 columns: one column per thread of a 128-group)
-        constexpr int TR = THREADS / 128;
-        const int tc = tid & 127, tr = tid >> 7;
-        for (int r0 = tr; r0 < n; r0 += 6 * TR) {
-            double v[6];
-#pragma unroll
-            for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; v[u] = (r < n && tc < n) ? p.Hi[(size_t)r * n + tc] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; if (r < n && tc < n) sHi[r * LD + tc] = v[u]; }
-        }
-        const int npad = LD - n;            // zero columns n .. LD-1
-        for (int idx = tid; idx < n * npad; idx += THREADS) { const int r = idx / npad; sHi[r * LD + n + (idx - r * npad)] = 0.0; }
-    }
-    for (int j = tid; j < NQ; j += THREADS) {
-        sLb[j] = (j < n) ? p.lbs[j] : -1e300;
-        sUb[j] = (j < n) ? p.ubs[j] : 1e300;
-        sD[j] = (j < n) ? p.d[j] : 0.0;
-    }
-    for (int idx = tid; idx < (nx + 1) * NQ; idx += THREADS) {
-        const int c = idx / NQ, j = idx - c * NQ;
-        sKu[idx] = (j < n) ? p.KuT[(size_t)c * p.NP + j] : 0.0;
-        if (!p.Cq) sFs[idx] = (j < n) ? p.FsT[(size_t)c * p.NP + j] : 0.0;
-    }
-    for (int idx = tid; idx < IPW * nx; idx += THREADS) {
-        const int l2 = idx / nx, c = idx - l2 * nx;
-        const bool v2 = slot0 + l2 < total;
-        const int i2 = v2 ? (p.qin ? p.qin[slot0 + l2] : slot0 + l2) : 0;
-        sX0[idx] = v2 ? p.x0[(size_t)i2 * nx + c] : 0.0;
-    }
+    // x0 of my instance: the group's lanes fetch it themselves (the instance index is already here: no second index load)
+    for (int c = g; c < nx; c += G) sX0[li * nx + c] = valid ? p.x0[(size_t)inst * nx + c] : 0.0;
     __syncthreads();
     PROF_MARK(0);
 
@@ -223,7 +202,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 #pragma unroll
             for (int j = 0; j < RPL; ++j) x[j] += sKu[c * NQ + ROWJ(j)] * xc;
         }
-        if (p.Cq) {         // c0 = [x0;1]' Cq [x0;1], rows a = g, g+G, .. of the form in lane g
+        {                   // c0 = [x0;1]' Cq [x0;1], rows a = g, g+G, .. of the form in lane g
             const int nx1 = nx + 1;
             for (int a = g; a < nx1; a += G) {
                 const double* cr = p.Cq + (size_t)a * nx1;
@@ -231,24 +210,13 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
                 for (int b = 0; b < nx; ++b) sa += cr[b] * sX0[li * nx + b];
                 c0 += sa * (a < nx ? sX0[li * nx + a] : 1.0);
             }
-        } else {
-            double q[RPL];
-#pragma unroll
-            for (int j = 0; j < RPL; ++j) q[j] = sFs[nx * NQ + ROWJ(j)];
-            for (int c = 0; c < nx; ++c) {
-                const double xc = sX0[li * nx + c];
-#pragma unroll
-                for (int j = 0; j < RPL; ++j) q[j] += sFs[c * NQ + ROWJ(j)] * xc;
-            }
-#pragma unroll
-            for (int j = 0; j < RPL; ++j) c0 += q[j] * x[j];
         }
         c0 = grp_sum<G>(c0);
     }
 
     // ---- active-set guess from the ADMM iterate (z at a bound and the scaled dual pushing outwards) ---
     unsigned mU = 0u, mL = 0u;
-    if (valid) {
+    if (!COLD && valid) {
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int row = ROWJ(j);
@@ -260,7 +228,6 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
                 // violates was measured and is slower (0.67 vs 0.58 ms per batch): the guess overshoots, the warm phase
                 // has to factor and prune it and more instances outgrow the first pass
                 // (the same guess for the heavy instances of the second pass only: also slower, 138 vs 146 M solves/s)
-                if (p.cold) continue;
                 if (zz[j] >= hi - tz && ww[j] > tw) mU |= 1u << j;
                 else if (zz[j] <= lo + tz && ww[j] < -tw) mL |= 1u << j;
             }
@@ -365,7 +332,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 
     PROF_MARK(1);
     // ---- warm phase (skipped by a wave none of whose instances has a guess: every cold start) -----------
-    if (__any(valid && (mU | mL) != 0u)) {
+    if (!COLD && __any(valid && (mU | mL) != 0u)) {
         // ordered list of the guessed set: lane g's rows after those of lanes < g
         const unsigned m = mU | mL;
         int* cntp = reinterpret_cast<int*>(myR);
@@ -535,7 +502,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     // one refinement of the multipliers against S itself (W is a product of rank-one updates), then
     // x = xu - Hi[:,A] lam on every row (rows in A land on their bound up to rounding; they are
     // reported as the bound itself and never tested for violation)
-    {
+    if (!COLD) {
         double e[NS], dl[NS];
         resid(e);
         w_times(e, dl);
@@ -552,16 +519,20 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         double best = 0.0; int code = -1;
         const unsigned m = mU | mL;
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {
+        for (int j = 0; j < RPL; ++j) {     // violation beyond the tolerance: x - (hi + tol) or (lo - tol) - x
             const int row = ROWJ(j);
-            const double hi = sUb[row], lo = sLb[row];
-            const double tol = 1e-12 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
-            const double vu = x[j] - hi, vl = lo - x[j];
+            const double2 bt = sBT[row];
+            const double vu = x[j] - bt.y, vl = bt.x - x[j];
             const double v = fmax(vu, vl);
-            if (!((m >> j) & 1u) && v > tol && v > best) { best = v; code = 2 * row + (vu > vl ? 1 : 0); }
+            if (!((m >> j) & 1u) && v > best) { best = v; code = 2 * row + (vu > vl ? 1 : 0); }
         }
         grp_max<G>(best, code);
         bool has = run && code >= 0;
+        PROF_MARK(9);
+        if (code >= 0) {                    // the violation itself: add the row's tolerance back
+            const double hi = sUb[code >> 1], lo = sLb[code >> 1];
+            best += 1e-12 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
+        }
         if (!__any(has)) break;
         if (has && ++guard > p.max_steps) { fail = true; why = 5; run = false; has = false; }
         const int pr = has ? (code >> 1) : 0;
@@ -596,6 +567,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
             grp_min<G>(t1, jb);
             const bool full = (t2 <= t1);
             const double t = inner ? (full ? t2 : t1) : 0.0;
+            PROF_MARK(10);
             // x -= t (sp Hi[:,p] - Hi[:,A] (sp r)),  lam_A -= t sp r
 #pragma unroll
             for (int i = 0; i < NS; ++i) myR[G * i + g] = r[i];
@@ -620,6 +592,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 #pragma unroll
             for (int i = 0; i < NS; ++i) lam[i] -= cp * r[i];
             accl += cp;
+            PROF_MARK(11);
             if (inner) ++steps;
             bool app = inner && full, drp = inner && !full;
             int pos = 0;
@@ -645,12 +618,15 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
                     if (ROW_OWNER(pr)) { if (upP) mU |= 1u << ROW_BIT(pr); else mL |= 1u << ROW_BIT(pr); }
                 }
             }
+            PROF_MARK(12);
             if (__any(drp)) {
+                PROF_CNT(14);
                 if (drp) viol -= t * d2;
                 drop(drp ? jb : 0, drp);
                 if (drp && ++guard > p.max_steps) { fail = true; why = 6; run = false; inner = false; }
             }
             wsync();
+            PROF_MARK(13);
         }
     }
 
@@ -738,19 +714,111 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
         }
     }
     PROF_MARK(6);
+#ifdef POLISH_PROF
+    if (lane == 0) for (int i = 0; i < 16; ++i) pacc_out[i] += pacc[i];
+#endif
+}
+
+// COLD: no (z, w) to start from -- the instantiation every default solve uses (it carries neither the iterate registers nor
+// the warm-phase code).
+template <int G, int RP, int KMAX, int THREADS, bool COLD>
+__global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
+    OCT_LAYOUT
+    (void)sLb; (void)sUb; (void)sD; (void)sBT; (void)sX0; (void)myR; (void)myV; (void)myA; (void)g; (void)li; (void)CH; (void)XCH; (void)NS; (void)RPL;
+    unsigned long long pacc[16] = {};
+    // ---- stage the shared data --------------------------------------------------------------
+    {   // Hi -> LDS.  The workgroup can do nothing else until this has landed, so the loads are as wide as they can be (16 bytes,
+        // contiguous over the workgroup) and all in flight before the first LDS write waits for one
+        if (!(n & 1)) {
+            const int hn = n >> 1, tot2 = n * hn;           // double2 elements
+            constexpr int U = 8;
+            for (int base = tid; base < tot2; base += U * THREADS) {
+                double2 v[U]; int off[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int idx = base + u * THREADS;
+                    const bool in = idx < tot2;
+                    const int r = in ? idx / hn : 0;
+                    off[u] = in ? r * LD + 2 * (idx - r * hn) : -1;
+                    v[u] = in ? *reinterpret_cast<const double2*>(p.Hi + (size_t)2 * idx) : make_double2(0.0, 0.0);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (off[u] >= 0) { sHi[off[u]] = v[u].x; sHi[off[u] + 1] = v[u].y; }
+            }
+        } else {
+            constexpr int TR = THREADS / 128;
+            const int tc = tid & 127, tr = tid >> 7;
+            for (int r0 = tr; r0 < n; r0 += 6 * TR) {
+                double v[6];
+#pragma unroll
+                for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; v[u] = (r < n && tc < n) ? p.Hi[(size_t)r * n + tc] : 0.0; }
+#pragma unroll
+                for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; if (r < n && tc < n) sHi[r * LD + tc] = v[u]; }
+            }
+        }
+        const int npad = LD - n;            // zero columns n .. LD-1
+        for (int idx = tid; idx < n * npad; idx += THREADS) { const int r = idx / npad; sHi[r * LD + n + (idx - r * npad)] = 0.0; }
+    }
+    for (int j = tid; j < NQ; j += THREADS) {
+        sLb[j] = (j < n) ? p.lbs[j] : -1e300;
+        sUb[j] = (j < n) ? p.ubs[j] : 1e300;
+        sD[j] = (j < n) ? p.d[j] : 0.0;
+        const double lo = (j < n) ? p.lbs[j] : -1e300, hi = (j < n) ? p.ubs[j] : 1e300;
+        const double tol = 1e-12 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
+        sBT[j] = make_double2(lo - tol, hi + tol);
+    }
+    {   // the map [Ku | ku]': (nx+1) rows of NQ, 16-byte loads
+        // (NP and NQ are multiples of 16), four in flight per thread
+        const int hq = NQ / 2, tot2 = (nx + 1) * hq;
+        constexpr int U = 4;
+        for (int base = tid; base < tot2; base += U * THREADS) {
+            double2 vk[U]; int off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * THREADS;
+                const bool in = idx < tot2;
+                const int c = in ? idx / hq : 0, j = 2 * (idx - c * hq);
+                off[u] = in ? c * NQ + j : -1;
+                const bool ld = in && j < p.NP;
+                vk[u] = ld ? *reinterpret_cast<const double2*>(p.KuT + (size_t)c * p.NP + j) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (off[u] >= 0) *reinterpret_cast<double2*>(sKu + off[u]) = vk[u];
+        }
+    }
+    // one block of IPW instances per workgroup (a contiguous block of the batch, or entries of a device-side queue).
+    // Persistent workgroups that stage once and walk several blocks were measured twice (round 1 with prefetch, round 2 as
+    // a plain loop): the loop around this much code costs 30 % in register allocation, more than the staging it saves.
+    const int total = p.qin ? *p.qin_count : p.B;
+    if ((int)blockIdx.x * IPW < total) oct_block<G, RP, KMAX, THREADS, COLD>(p, blockIdx.x, total, pacc);
+#ifdef POLISH_PROF
+    if (lane == 0 && p.prof) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 16; ++i) { atomicAdd(p.prof + (G >= 32 ? 16 : 0) + i, pacc[i]); if (i != 7 && i != 8 && i != 14) tot += pacc[i]; }
+        atomicMax(p.prof + (G >= 32 ? 16 : 0) + 15, tot);       // longest wave: calibrates the tick against the kernel time
+    }
+#endif
+}
+
+template <int G, int RP, int KMAX, int THREADS, bool COLD>
+int launch_oct_c(const PolParams& p, int ninst, hipStream_t st) {
+    constexpr int NQ = 2 * G * RP, LD = NQ | 1, IPW = THREADS / G;
+    if (!p.Cq) return -1;
+    const size_t x0s = (size_t)IPW * p.nx * 8;
+    const size_t xch = (size_t)IPW * KMAX * 20;
+    const size_t lds = ((size_t)p.n * LD + 5 * NQ + (size_t)(p.nx + 1) * NQ) * 8 + (x0s > xch ? x0s : xch);
+    if (lds > 160 * 1024) return -1;
+    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS, COLD>), lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS, COLD>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
+    return (int)hipGetLastError();
 }
 
 template <int G, int RP, int KMAX, int THREADS>
 int launch_oct(const PolParams& p, int ninst, hipStream_t st) {
-    constexpr int NQ = 2 * G * RP, LD = NQ | 1, IPW = THREADS / G;
-    const size_t stage = (size_t)(2 * (p.nx + 1) * NQ + IPW * p.nx) * 8;
-    const size_t xch = (size_t)IPW * KMAX * 20;
-    const size_t lds = ((size_t)p.n * LD + 3 * NQ) * 8 + (stage > xch ? stage : xch);
-    if (lds > 160 * 1024) return -1;
-    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS>), lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
-    return (int)hipGetLastError();
+    return p.cold ? launch_oct_c<G, RP, KMAX, THREADS, true>(p, ninst, st) : launch_oct_c<G, RP, KMAX, THREADS, false>(p, ninst, st);
 }
 
 // row pairs per lane: n <= 2 G RP
@@ -880,9 +948,20 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
         a.qin = order; a.qin_count = count;
     }
     if (stop_after == 2) return 0;
-    int rc = launch_oct_rp<8, 16, 512>(a, p.B, st);
+    // fewer blocks of 64 instances than the device has CUs (a 1/8 shard of the headline batch): half-size workgroups, so that
+    // the launch covers twice as many CUs with one wave per SIMD -- the latency of the heaviest block is what such a launch lasts
+    int rc = p.B < 64 * 256 ? launch_oct_rp<8, 16, 256>(a, p.B, st) : launch_oct_rp<8, 16, 512>(a, p.B, st);
     if (rc != 0 || stop_after == 1) return rc;
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
     return launch_oct_rp<32, 32, 512>(b, p.B, st);
 }
+#ifdef OCT_PROBE
+namespace { 
+template __global__ void polish_oct_kernel<8, 8, 16, 768, true>(PolParams);
+template __global__ void polish_oct_kernel<8, 8, 16, 1024, true>(PolParams);
+template __global__ void polish_oct_kernel<32, 2, 32, 1024, true>(PolParams);
+template __global__ void polish_oct_kernel<16, 4, 16, 1024, true>(PolParams);
+template __global__ void polish_oct_kernel<16, 4, 32, 1024, true>(PolParams);
+}
+#endif
