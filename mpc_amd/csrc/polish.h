@@ -17,6 +17,8 @@ struct PolParams {
     double rho;
     long st_nn, st_k, st_np, st_n;  // one model per instance: element strides of (Hs,Hi), (FsT,KuT), (lbs,ubs), d; 0 = shared
     const int* mflag;              // factorisation failure flags: one per model (st_nn != 0) or the shared model's single flag
+    int handoff;                   // 1 (cold solves): an instance whose slot list is full leaves its active set in (z, w) for the next pass
+    int mixed;                     // 1: only instances with need_big == 3 (handed over by the previous pass) have a guess in (z, w)
     int cold; int admm_ran; const double* Cq;                      // 1: no (z, w) to start from -- begin with the empty active set
     const int *qin, *qin_count;    // instance queue to take the work from (nullptr: instances 0..B-1)
     int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)
@@ -25,3 +27,6 @@ struct PolParams {
 
 // fast path; returns MPCQP_ENOTIMPL if the shape does not fit it (the caller then uses the wave kernel)
 int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, int stop_after = 0);   // diagnostics: 1 = after the first pass, 2 = after the cold-start ordering
+// third chance: a whole wave per instance and up to 64 active rows with the same explicit-inverse kernel (the queue of the
+// second pass in p.qin, what outgrows it into p.qout); -1 if the shape does not fit
+int launch_polish_oct64(const PolParams& p, hipStream_t st);

@@ -559,6 +559,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     p.Cq = per_model ? nullptr : h->Cq;
     p.mflag = per_model ? h->mflag : h->flag_dev;
     p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
+    p.handoff = 0; p.mixed = 0;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
     // int workspace beyond [iters | need_big | converged]: two instance queues and their counters
     int* q1 = h->it_ws + 3 * (size_t)h->Bcap;
@@ -591,7 +592,8 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
         // what the two fast passes could not finish: up to 64 active rows with four waves per workgroup (eight waves per
         // CU), the rest (queue 1 is free again) with one wave per workgroup and room for every row
         p.pass = 1; p.qin = q2; p.qin_count = counters + 1; p.qout = q1; p.qout_count = counters + 3;
-        rc = launch_pol<64, 4>(p, st, 512);
+        rc = launch_polish_oct64(p, st);
+        if (rc < 0) rc = launch_pol<64, 4>(p, st, 512);
         if (rc == 0) {
             p.qin = q1; p.qin_count = counters + 3; p.qout = nullptr; p.qout_count = nullptr;
             rc = launch_pol<128, 1>(p, st, 512);

@@ -57,7 +57,8 @@ __device__ __forceinline__ double grp_sum(double v) {
     v += dpp_d<DPP_XOR2>(v);
     v += dpp_d<DPP_HMIRROR>(v);
     if (G >= 16) v += dpp_d<DPP_ROR8>(v);
-    if (G == 32) v += __shfl_xor(v, 16);        // across the two DPP rows of the group
+    if (G >= 32) v += __shfl_xor(v, 16);        // across the DPP rows of the group
+    if (G == 64) v += __shfl_xor(v, 32);
     return v;
 }
 template <int CTRL>
@@ -70,8 +71,12 @@ template <int G>
 __device__ __forceinline__ void grp_min(double& t, int& j) {
     min_step<DPP_XOR1>(t, j); min_step<DPP_XOR2>(t, j); min_step<DPP_HMIRROR>(t, j);
     if (G >= 16) min_step<DPP_ROR8>(t, j);
-    if (G == 32) {
+    if (G >= 32) {
         const double ot = __shfl_xor(t, 16); const int oj = __shfl_xor(j, 16);
+        if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
+    }
+    if (G == 64) {
+        const double ot = __shfl_xor(t, 32); const int oj = __shfl_xor(j, 32);
         if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
     }
 }
@@ -81,7 +86,8 @@ template <int G>
 __device__ __forceinline__ int grp_imin(int j) {
     imin_step<DPP_XOR1>(j); imin_step<DPP_XOR2>(j); imin_step<DPP_HMIRROR>(j);
     if (G >= 16) imin_step<DPP_ROR8>(j);
-    if (G == 32) { const int oj = __shfl_xor(j, 16); j = oj < j ? oj : j; }
+    if (G >= 32) { const int oj = __shfl_xor(j, 16); j = oj < j ? oj : j; }
+    if (G == 64) { const int oj = __shfl_xor(j, 32); j = oj < j ? oj : j; }
     return j;
 }
 template <int CTRL>
@@ -93,8 +99,12 @@ template <int G>
 __device__ __forceinline__ void grp_max(double& v, int& code) {
     max_step<DPP_XOR1>(v, code); max_step<DPP_XOR2>(v, code); max_step<DPP_HMIRROR>(v, code);
     if (G >= 16) max_step<DPP_ROR8>(v, code);
-    if (G == 32) {
+    if (G >= 32) {
         const double ov = __shfl_xor(v, 16); const int oc = __shfl_xor(code, 16);
+        if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
+    }
+    if (G == 64) {
+        const double ov = __shfl_xor(v, 32); const int oc = __shfl_xor(code, 32);
         if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
     }
 }
@@ -167,7 +177,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
     for (int j = 0; j < RPL; ++j) { zz[j] = 0.0; ww[j] = 0.0; }
     double* zb = p.z + (size_t)inst * p.NP;
     double* wb = p.w + (size_t)inst * p.NP;
-    if (!COLD && valid) {
+    if (!COLD && valid && (!p.mixed || p.need_big[inst] == 3)) {
         if (!(n & 1)) {     // pairs never straddle n: 16-byte loads
 #pragma unroll
             for (int jj = 0; jj < RP; ++jj) {
@@ -248,7 +258,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #pragma unroll
         for (int c = 0; c < KMAX; ++c) W[i][c] = 0.0;
     }
-    unsigned live = 0u;                 // occupied slots (same in the 8 lanes)
+    unsigned long long live = 0ull;     // occupied slots (same in the G lanes)
     int khi = 0;                        // 1 + highest slot ever occupied
     bool over = false, fail = false;
     int steps = 0, why = 0;
@@ -319,7 +329,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
                 }
         }
         if (d) {
-            live &= ~(1u << jb);
+            live &= ~(1ull << jb);
 #pragma unroll
             for (int i = 0; i < NS; ++i)
                 if (G * i + g == jb) { lam[i] = 0.0; rhs[i] = 0.0; sgO[i] = 0.0; raO[i] = 0; }
@@ -368,7 +378,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             sgO[i] = in ? myR[a] : 0.0;
             rhs[i] = in ? myV[a] : 0.0;
         }
-        live = k0 >= 32 ? 0xFFFFFFFFu : ((1u << k0) - 1u);
+        live = k0 >= 64 ? ~0ull : ((1ull << k0) - 1ull);
         khi = k0;
         wsync();
         // W = S^-1 by successive bordering in list order
@@ -398,7 +408,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             rank1(coef, min(t + 1, k0));
             wsync();
         }
-        if (fail) { live = 0u; }
+        if (fail) { live = 0ull; }
         PROF_MARK(2);
         // multipliers on the guessed set; release the wrong-signed ones and solve again
         for (;;) {
@@ -597,7 +607,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             bool app = inner && full, drp = inner && !full;
             int pos = 0;
             if (app) {
-                pos = __ffs(~live) - 1;
+                pos = __ffsll((long long)~live) - 1;
                 if (pos < 0 || pos >= KMAX) { over = true; why = 3; run = false; app = false; pos = 0; }
                 inner = false;
             }
@@ -614,7 +624,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #pragma unroll
                     for (int i = 0; i < NS; ++i)
                         if (G * i + g == pos) { lam[i] = accl; rhs[i] = rp; raO[i] = pr; sgO[i] = sp; }
-                    live |= 1u << pos;
+                    live |= 1ull << pos;
                     if (ROW_OWNER(pr)) { if (upP) mU |= 1u << ROW_BIT(pr); else mL |= 1u << ROW_BIT(pr); }
                 }
             }
@@ -713,6 +723,19 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             if (p.info.polish_steps) p.info.polish_steps[inst] = steps;
         }
     }
+    if (p.handoff && p.qout && valid && over && why == 3) {
+        // the slot list is full but consistent (a dual-feasible working set): leave it in (z, w) -- a cold solve has no other use
+        // for that state -- as the next pass's starting guess, so that it continues instead of starting again
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) {
+            const int row = ROWJ(j);
+            if (row < n) {
+                const bool up = (mU >> j) & 1u, lo = (mL >> j) & 1u;
+                zb[row] = up ? sUb[row] : (lo ? sLb[row] : 0.0);
+                wb[row] = up ? 1.0 : (lo ? -1.0 : 0.0);
+            }
+        }
+    }
     PROF_MARK(6);
 #ifdef POLISH_PROF
     if (lane == 0) for (int i = 0; i < 16; ++i) pacc_out[i] += pacc[i];
@@ -726,6 +749,12 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     OCT_LAYOUT
     (void)sLb; (void)sUb; (void)sD; (void)sBT; (void)sX0; (void)myR; (void)myV; (void)myA; (void)g; (void)li; (void)CH; (void)XCH; (void)NS; (void)RPL;
     unsigned long long pacc[16] = {};
+    // one block of IPW instances per workgroup (a contiguous block of the batch, or entries of a device-side queue; launches
+    // over a queue are sized for the whole batch, so most of their workgroups leave here).
+    // Persistent workgroups that stage once and walk several blocks were measured twice (round 1 with prefetch, round 2 as
+    // a plain loop): the loop around this much code costs 30 % in register allocation, more than the staging it saves.
+    const int total = p.qin ? *p.qin_count : p.B;
+    if ((int)blockIdx.x * IPW >= total) return;
     // ---- stage the shared data --------------------------------------------------------------
     {   // Hi -> LDS.  The workgroup can do nothing else until this has landed, so the loads are as wide as they can be (16 bytes,
         // contiguous over the workgroup) and all in flight before the first LDS write waits for one
@@ -788,11 +817,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
                 if (off[u] >= 0) *reinterpret_cast<double2*>(sKu + off[u]) = vk[u];
         }
     }
-    // one block of IPW instances per workgroup (a contiguous block of the batch, or entries of a device-side queue).
-    // Persistent workgroups that stage once and walk several blocks were measured twice (round 1 with prefetch, round 2 as
-    // a plain loop): the loop around this much code costs 30 % in register allocation, more than the staging it saves.
-    const int total = p.qin ? *p.qin_count : p.B;
-    if ((int)blockIdx.x * IPW < total) oct_block<G, RP, KMAX, THREADS, COLD>(p, blockIdx.x, total, pacc);
+    oct_block<G, RP, KMAX, THREADS, COLD>(p, blockIdx.x, total, pacc);
 #ifdef POLISH_PROF
     if (lane == 0 && p.prof) {
         unsigned long long tot = 0;
@@ -898,7 +923,7 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
 // start again.  The others are laid out largest bucket first.  Every block derives the bucket offsets from the finished
 // histogram itself; cursors (zeroed by the caller) hand out the places inside a bucket.
 __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, const int* bins, int* cursors, int* order, int* q1,
-                                                           int* count, int* q1_count, int B, int route) {
+                                                           int* count, int* q1_count, int* need_big, int B, int route) {
     __shared__ int hist[NBIN], base[NBIN], start[NBIN];
     const int tid = threadIdx.x, inst = blockIdx.x * 256 + tid;
     if (tid < NBIN) {
@@ -920,7 +945,10 @@ __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, cons
     __syncthreads();
     if (tid < NBIN && hist[tid]) base[tid] = start[tid] + atomicAdd(&cursors[tid], hist[tid]);
     __syncthreads();
-    if (inst < B) (key >= route ? q1 : order)[base[key] + local] = inst;
+    if (inst < B) {
+        (key >= route ? q1 : order)[base[key] + local] = inst;
+        if (key >= route) need_big[inst] = 0;       // routed past the first pass: nothing is handed over in (z, w)
+    }
 }
 
 // The two fast passes: pass A (8 lanes per instance, KMAX = 16) takes the whole batch -- in cold-start order, minus the
@@ -933,9 +961,13 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (e != hipSuccess) return (int)e;
     PolParams a = p;
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
+    a.handoff = p.cold; a.mixed = 0;
     const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
     const size_t kl = ((size_t)kp * nq + 2 * nq + 64 * (size_t)kp) * sizeof(double);
-    if (p.cold && p.B >= 4096 && kl <= 64 * 1024) {
+    // the ordering pays once the device is full (lock-step efficiency); below that a launch lasts as long as its heaviest
+    // block either way and the two extra kernels only add to it (measured, per solve: 32,768 instances 276 us with / 322 us
+    // without; 16,384: 242 / 223; 8,192: 219 / 200)
+    if (p.cold && p.B >= 24576 && kl <= 64 * 1024) {
         // keys in q2 (written again only by the second pass), buckets / cursors / count in the counter block,
         // the order in the last slot of the int workspace
         int* keys = q2; int* order = counters + 96;
@@ -943,7 +975,7 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
         hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins);
         const int route = std::min(NBIN, 2 * 16 / 3);              // first-pass capacity 16 rows; swept 8..14: 10 is best
         hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, bins, cursors, order, q1, count,
-                           counters, p.B, route);
+                           counters, p.need_big, p.B, route);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
         a.qin = order; a.qin_count = count;
     }
@@ -954,6 +986,8 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (rc != 0 || stop_after == 1) return rc;
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
+    b.handoff = 0; b.mixed = p.cold;     // (handing the 32-row set on to the 64-lane pass was measured: no gain, its steps are as cheap as the re-build)
+    if (p.cold) b.cold = 0;         // the warm-capable instantiation: instances the first pass handed over continue from its set
     return launch_oct_rp<32, 32, 512>(b, p.B, st);
 }
 #ifdef OCT_PROBE
@@ -965,3 +999,10 @@ template __global__ void polish_oct_kernel<16, 4, 16, 1024, true>(PolParams);
 template __global__ void polish_oct_kernel<16, 4, 32, 1024, true>(PolParams);
 }
 #endif
+
+int launch_polish_oct64(const PolParams& p, hipStream_t st) {
+    if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
+    PolParams c = p;
+    c.handoff = 0; c.mixed = 0;
+    return launch_oct_rp<64, 64, 512>(c, p.B, st);
+}
