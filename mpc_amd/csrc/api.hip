@@ -41,6 +41,8 @@ int ensure_batch(mpcqp_handle h, int B) {
     TRY(dev_alloc(h, &h->it_ws, (size_t)need * 6 + 96));   // iters | need_big | converged | queue 1 | queue 2 | counters, buckets | cold-start order
     TRY(dev_alloc(h, &h->rp_ws, (size_t)need));
     TRY(dev_alloc(h, &h->rd_ws, (size_t)need));
+    TRY(dev_alloc(h, &h->hbuf1, (size_t)need * (16 * 16 + 4 * 16 + 2)));
+    TRY(dev_alloc(h, &h->hbuf2, (size_t)(need / 4) * (32 * 32 + 4 * 32 + 2)));
     h->Bcap = need;
     h->has_state = false;
     return MPCQP_OK;
@@ -134,7 +136,7 @@ int mpcqp_destroy(mpcqp_handle h) {
     (void)hipSetDevice(h->dev);
     void* ptrs[] = {h->Gam, h->QG, h->Phi, h->H, h->F, h->f0, h->d, h->Hs, h->M, h->Hi, h->W1, h->W2, h->Fs1,
                     h->Ku1, h->Cq, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev, h->mflag,
-                    h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws};
+                    h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws, h->hbuf1, h->hbuf2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     delete h;
     return MPCQP_OK;

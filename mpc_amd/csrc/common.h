@@ -52,6 +52,7 @@ struct mpcqp_handle_s {
     double *b0ws = nullptr;                // [Bcap][NP]: ADMM offsets b0, fragment order per 16 instances
     int *it_ws = nullptr;                  // [6 Bcap + 96]: iters | need_big | converged | polish queue 1 | queue 2 | counters, buckets (96) | cold-start order
     double *rp_ws = nullptr, *rd_ws = nullptr;
+    double *hbuf1 = nullptr, *hbuf2 = nullptr;   // hand-over of the working state between active-set passes: [Bcap][16*16+66], [Bcap/4][32*32+130]
     bool assembled = false, factored = false, has_state = false;
     std::string err;
 };

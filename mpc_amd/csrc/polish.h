@@ -17,8 +17,16 @@ struct PolParams {
     double rho;
     long st_nn, st_k, st_np, st_n;  // one model per instance: element strides of (Hs,Hi), (FsT,KuT), (lbs,ubs), d; 0 = shared
     const int* mflag;              // factorisation failure flags: one per model (st_nn != 0) or the shared model's single flag
-    int handoff;                   // 1 (cold solves): an instance whose slot list is full leaves its active set in (z, w) for the next pass
-    int mixed;                     // 1: only instances with need_big == 3 (handed over by the previous pass) have a guess in (z, w)
+    // hand-over between the passes of a cold solve: an instance whose slot list is full (need_big == 3) leaves its whole
+    // working state -- S^-1, multipliers, right-hand sides, rows, step count: K*K + 4K + 2 doubles for K slots -- in hand_out
+    // at the index of its place in the output queue; the next pass (twice the slots) reads it from hand_in at the index of
+    // its place in the input queue and continues instead of starting again.  nullptr = no hand-over.
+    double* hand_out; int hand_out_cap;     // entries available in hand_out (beyond that the next pass starts cold)
+    const double* hand_in;
+    int hand_zw;                   // giver: leave the full working SET in (z, w) (z on the bound, w = +-1) for the wave-per-instance
+                                   // kernel, whose factorisation is a Cholesky factor; receiver (that kernel): instances with
+                                   // need_big == 3 start from the guess in (z, w) although the solve is cold
+    double *hand_buf1, *hand_buf2; int hand_cap2;      // the handle's buffers (first -> second pass, second -> third pass)
     int cold; int admm_ran; const double* Cq;                      // 1: no (z, w) to start from -- begin with the empty active set
     const int *qin, *qin_count;    // instance queue to take the work from (nullptr: instances 0..B-1)
     int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)

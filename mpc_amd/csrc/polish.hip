@@ -201,7 +201,8 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
         const int j = lane + 64 * q;
         if (j < n) {
             lo[q] = p.lbs[j]; hi[q] = p.ubs[j];
-            const double zz = p.cold ? 0.0 : zb[j], ww = p.cold ? 0.0 : wb[j];
+            const bool guess = !p.cold || (p.hand_zw && p.need_big[inst] == 3);     // a kept iterate, or the set the last pass left
+            const double zz = guess ? zb[j] : 0.0, ww = guess ? wb[j] : 0.0;
             x[q] = zz;
             lam[q] = p.rho * ww;
             // (z, w) are recovered from the kernel's (v, c) state, so "at the bound" and "w != 0"
@@ -559,7 +560,8 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     p.Cq = per_model ? nullptr : h->Cq;
     p.mflag = per_model ? h->mflag : h->flag_dev;
     p.qin = nullptr; p.qin_count = nullptr; p.qout = nullptr; p.qout_count = nullptr;
-    p.handoff = 0; p.mixed = 0;
+    p.hand_in = nullptr; p.hand_out = nullptr; p.hand_out_cap = 0; p.hand_zw = 0;
+    p.hand_buf1 = h->hbuf1; p.hand_buf2 = h->hbuf2; p.hand_cap2 = h->Bcap / 4;
     if (h->dims.nx > 64) { h->err = "polish: nx > 64 not supported in this build"; return MPCQP_ENOTIMPL; }
     // int workspace beyond [iters | need_big | converged]: two instance queues and their counters
     int* q1 = h->it_ws + 3 * (size_t)h->Bcap;
@@ -596,6 +598,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
         if (rc < 0) rc = launch_pol<64, 4>(p, st, 512);
         if (rc == 0) {
             p.qin = q1; p.qin_count = counters + 3; p.qout = nullptr; p.qout_count = nullptr;
+            p.hand_zw = p.cold;         // the 64-row pass leaves its working set as the guess
             rc = launch_pol<128, 1>(p, st, 512);
         }
     } else if (rc < 0) {

@@ -177,7 +177,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
     for (int j = 0; j < RPL; ++j) { zz[j] = 0.0; ww[j] = 0.0; }
     double* zb = p.z + (size_t)inst * p.NP;
     double* wb = p.w + (size_t)inst * p.NP;
-    if (!COLD && valid && (!p.mixed || p.need_big[inst] == 3)) {
+    if (!COLD && valid) {
         if (!(n & 1)) {     // pairs never straddle n: 16-byte loads
 #pragma unroll
             for (int jj = 0; jj < RP; ++jj) {
@@ -521,6 +521,43 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         x_minus(lam);
     }
 
+    // ---- hand-over: continue from the state the previous pass left when its slot list was full ----------------------
+    if (p.hand_in) {
+        constexpr int HK = KMAX / 2;                    // the previous pass has half the slots
+        constexpr int HENT = HK * HK + 4 * HK + 2;
+        const bool handed = valid && !fail && p.need_big[inst] == 3;
+        if (__any(handed)) {
+            if (handed) {
+                const double* hb = p.hand_in + (size_t)(slot0 + li) * HENT;
+#pragma unroll
+                for (int i = 0; i < NS; ++i) {
+                    const int a = G * i + g;
+                    if (a < HK) {
+#pragma unroll
+                        for (int c = 0; c < HK; c += 2) {
+                            const double2 v = *reinterpret_cast<const double2*>(hb + a * HK + c);
+                            W[i][c] = v.x; W[i][c + 1] = v.y;
+                        }
+                        lam[i] = hb[HK * HK + a]; rhs[i] = hb[HK * HK + HK + a]; sgO[i] = hb[HK * HK + 2 * HK + a];
+                        raO[i] = (int)hb[HK * HK + 3 * HK + a];
+                        myA[a] = raO[i]; myV[a] = sgO[i];
+                    }
+                }
+                steps = (int)hb[HK * HK + 4 * HK];
+                live = (1ull << HK) - 1ull; khi = HK;
+            }
+            wsync();
+            if (handed) {
+                for (int a = 0; a < HK; ++a) {
+                    const int row = myA[a];
+                    if (ROW_OWNER(row)) { if (myV[a] > 0.0) mU |= 1u << ROW_BIT(row); else mL |= 1u << ROW_BIT(row); }
+                }
+            }
+            wsync();
+            x_minus(lam);           // x = xu - Hi[:,A] lam (lam = 0 and no rows where nothing was handed over)
+        }
+    }
+
     PROF_MARK(4);
     // ---- main phase: add the most violated bound until none is violated ----------------------------
     bool run = valid && !over && !fail;
@@ -576,6 +613,9 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             }
             grp_min<G>(t1, jb);
             const bool full = (t2 <= t1);
+            // a full step needs a free slot for p: without one stop BEFORE the step, so that (x, lam, W) stay the consistent
+            // state of the current working set -- that state is what the next pass is handed
+            if (inner && full && live == (KMAX == 64 ? ~0ull : ((1ull << (KMAX & 63)) - 1ull))) { over = true; why = 3; run = false; inner = false; }
             const double t = inner ? (full ? t2 : t1) : 0.0;
             PROF_MARK(10);
             // x -= t (sp Hi[:,p] - Hi[:,A] (sp r)),  lam_A -= t sp r
@@ -657,9 +697,11 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
     PROF_MARK(5);
     // ---- outputs --------------------------------------------------------------------------------------
     const bool okk = valid && !over && !fail;
+    int qslot = -1;
     if (valid && g == 0) {
-        p.need_big[inst] = okk ? 0 : (why ? why : 7);
-        if (!okk && p.qout) p.qout[atomicAdd(p.qout_count, 1)] = inst;      // queue for the next, larger pass
+        if (!okk && p.qout) { qslot = atomicAdd(p.qout_count, 1); p.qout[qslot] = inst; }      // queue for the next, larger pass
+        const bool give = over && why == 3 && qslot >= 0 && ((p.hand_out && qslot < p.hand_out_cap) || p.hand_zw);
+        p.need_big[inst] = okk ? 0 : (why == 3 && !give ? 9 : (why ? why : 7));       // 3 = handed over, 9 = list full, start again
     }
     double dual = 0.0;
 #pragma unroll
@@ -723,9 +765,24 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             if (p.info.polish_steps) p.info.polish_steps[inst] = steps;
         }
     }
-    if (p.handoff && p.qout && valid && over && why == 3) {
-        // the slot list is full but consistent (a dual-feasible working set): leave it in (z, w) -- a cold solve has no other use
-        // for that state -- as the next pass's starting guess, so that it continues instead of starting again
+    if (p.hand_out && p.qout && valid && over && why == 3) {
+        // the slot list is full but consistent (a dual-feasible working set with its inverse): hand the state to the next pass
+        constexpr int HENT = KMAX * KMAX + 4 * KMAX + 2;
+        qslot = __shfl(qslot, lane & ~(G - 1));
+        if (qslot < p.hand_out_cap) {
+            double* hb = p.hand_out + (size_t)qslot * HENT;
+#pragma unroll
+            for (int i = 0; i < NS; ++i) {
+                const int a = G * i + g;
+#pragma unroll
+                for (int c = 0; c < KMAX; c += 2) *reinterpret_cast<double2*>(hb + a * KMAX + c) = make_double2(W[i][c], W[i][c + 1]);
+                hb[KMAX * KMAX + a] = lam[i]; hb[KMAX * KMAX + KMAX + a] = rhs[i]; hb[KMAX * KMAX + 2 * KMAX + a] = sgO[i];
+                hb[KMAX * KMAX + 3 * KMAX + a] = (double)raO[i];
+            }
+            if (g == 0) hb[KMAX * KMAX + 4 * KMAX] = (double)steps;
+        }
+    }
+    if (p.hand_zw && p.qout && valid && over && why == 3) {
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int row = ROWJ(j);
@@ -880,15 +937,38 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
     double* sLb = sKu + (size_t)KP * NQ;                // (NQ) padded rows can never be violated
     double* sUb = sLb + NQ;
     double* sX = sUb + NQ;                              // (64, KP): [x0; 1; 0..] of this block's instances
-    for (int idx = tid; idx < KP * NQ; idx += 256) {
-        const int k = idx / NQ, j = idx - k * NQ;
-        sKu[idx] = (k <= nx && j < n) ? p.KuT[(size_t)k * p.NP + j] : 0.0;
+    {   // stage with every load in flight before the first LDS write: 16-byte loads of the map (NP, NQ multiples of 16)
+        const int hq = NQ / 2, tot2 = KP * hq;
+        constexpr int U = 4;
+        for (int base = tid; base < tot2; base += U * 256) {
+            double2 v[U]; int off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                const bool in = idx < tot2;
+                const int k = in ? idx / hq : 0, j = 2 * (idx - k * hq);
+                off[u] = in ? k * NQ + j : -1;
+                v[u] = (in && k <= nx && j < p.NP) ? *reinterpret_cast<const double2*>(p.KuT + (size_t)k * p.NP + j) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (off[u] >= 0) *reinterpret_cast<double2*>(sKu + off[u]) = v[u];
+        }
     }
     for (int j = tid; j < NQ; j += 256) { sLb[j] = j < n ? p.lbs[j] : -1e300; sUb[j] = j < n ? p.ubs[j] : 1e300; }
-    for (int idx = tid; idx < 64 * KP; idx += 256) {
-        const int l = idx / KP, k = idx - l * KP;
-        const int i2 = blockIdx.x * 64 + l;
-        sX[idx] = (i2 < p.B) ? (k < nx ? p.x0[(size_t)i2 * nx + k] : (k == nx ? 1.0 : 0.0)) : 0.0;
+    {
+        constexpr int U = 4;
+        for (int base = tid; base < 64 * KP; base += U * 256) {
+            double v[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = base + u * 256;
+                const int l = idx / KP, k = idx - l * KP;
+                const int i2 = blockIdx.x * 64 + l;
+                v[u] = (idx < 64 * KP && i2 < p.B) ? (k < nx ? p.x0[(size_t)i2 * nx + k] : (k == nx ? 1.0 : 0.0)) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (base + u * 256 < 64 * KP) sX[base + u * 256] = v[u];
+        }
     }
     if (tid < NBIN) hist[tid] = 0;
     __syncthreads();
@@ -961,7 +1041,7 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (e != hipSuccess) return (int)e;
     PolParams a = p;
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
-    a.handoff = p.cold; a.mixed = 0;
+    a.hand_in = nullptr; a.hand_out = p.cold ? p.hand_buf1 : nullptr; a.hand_out_cap = p.B; a.hand_zw = 0;
     const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
     const size_t kl = ((size_t)kp * nq + 2 * nq + 64 * (size_t)kp) * sizeof(double);
     // the ordering pays once the device is full (lock-step efficiency); below that a launch lasts as long as its heaviest
@@ -973,7 +1053,11 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
         int* keys = q2; int* order = counters + 96;
         int* bins = counters + 16; int* cursors = bins + NBIN; int* count = counters + 2;
         hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins);
-        const int route = std::min(NBIN, 2 * 16 / 3);              // first-pass capacity 16 rows; swept 8..14: 10 is best
+        // routing past the first pass (buckets >= route start in the second): worth it only while an instance that outgrows
+        // the first pass has to start again (warm solves: first-pass capacity 16 rows, final set ~1.5 x key; swept 8..14: 10 is
+        // best).  With the hand-over of cold solves every instance starts in the first pass and continues where it stopped
+        // (65,536 instances: 402 us routed at 10, 383 us unrouted with the set handed over, 375 us with the whole state)
+        const int route = a.hand_out ? NBIN : std::min(NBIN, 2 * 16 / 3);
         hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, bins, cursors, order, q1, count,
                            counters, p.need_big, p.B, route);
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
@@ -986,8 +1070,7 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (rc != 0 || stop_after == 1) return rc;
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
-    b.handoff = 0; b.mixed = p.cold;     // (handing the 32-row set on to the 64-lane pass was measured: no gain, its steps are as cheap as the re-build)
-    if (p.cold) b.cold = 0;         // the warm-capable instantiation: instances the first pass handed over continue from its set
+    b.hand_in = a.hand_out; b.hand_out = p.cold ? p.hand_buf2 : nullptr; b.hand_out_cap = p.hand_cap2; b.hand_zw = 0;
     return launch_oct_rp<32, 32, 512>(b, p.B, st);
 }
 #ifdef OCT_PROBE
@@ -1003,6 +1086,6 @@ template __global__ void polish_oct_kernel<16, 4, 32, 1024, true>(PolParams);
 int launch_polish_oct64(const PolParams& p, hipStream_t st) {
     if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
     PolParams c = p;
-    c.handoff = 0; c.mixed = 0;
+    c.hand_in = p.cold ? p.hand_buf2 : nullptr; c.hand_out = nullptr; c.hand_out_cap = 0; c.hand_zw = p.cold;
     return launch_oct_rp<64, 64, 512>(c, p.B, st);
 }
