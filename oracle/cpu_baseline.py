@@ -27,6 +27,8 @@ def load():
         lib.qp_ipm_solve.restype = C.c_int
         lib.qp_ipm_solve.argtypes = [C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, C.c_int, C.c_double, C.c_double,
                                      C.c_double, ip, dp]
+        lib.qp_activeset_batch_box.restype = C.c_int
+        lib.qp_activeset_batch_box.argtypes = [C.c_int, C.c_int, C.c_int, dp, dp, dp, dp, dp, dp, dp, ip, C.c_int]
         lib.qp_ipm_worksize.restype = C.c_long
         lib.qp_ipm_worksize.argtypes = [C.c_int, C.c_int]
         _LIB = lib
@@ -49,6 +51,25 @@ def solve_batch_box(H, F, f0, lb, ub, x0, nthreads=1, abstol=1e-7, reltol=1e-6, 
     bad = lib.qp_ipm_batch_box(n, nx, B, _p(H), _p(F), _p(f0), _p(lb), _p(ub), _p(x0), _p(U),
                                it.ctypes.data_as(C.POINTER(C.c_int)), int(nthreads), abstol, reltol, feastol)
     return U, it, bad, time.perf_counter() - t
+
+
+def solve_batch_box_activeset(H, F, f0, lb, ub, x0, nthreads=1):
+    """The GPU's own algorithm on the host (oracle/qp_activeset.c): dual active-set method on the shared inverse, exact
+    minimiser.  The inverse is formed once (NumPy), as the GPU's factor kernel does once per model and outside its timed
+    solve.  Returns (U, steps, n_failed, seconds)."""
+    lib = load()
+    H, F, f0, lb, ub, x0 = [np.ascontiguousarray(a, dtype=np.float64) for a in (H, F, f0, lb, ub, x0)]
+    n, nx = F.shape
+    B = x0.shape[0]
+    d = 1.0 / np.sqrt(np.diag(H))                   # Jacobi scaling before the inversion, as on the GPU
+    Hs = H * d[:, None] * d[None, :]
+    Hi = np.ascontiguousarray(np.linalg.inv(0.5 * (Hs + Hs.T)) * d[:, None] * d[None, :])
+    Hi = np.ascontiguousarray(0.5 * (Hi + Hi.T))
+    U = np.zeros((B, n)); st = np.zeros(B, dtype=np.int32)
+    t = time.perf_counter()
+    bad = lib.qp_activeset_batch_box(n, nx, B, _p(Hi), _p(F), _p(f0), _p(lb), _p(ub), _p(x0), _p(U),
+                                     st.ctypes.data_as(C.POINTER(C.c_int)), int(nthreads))
+    return U, st, bad, time.perf_counter() - t
 
 
 def solve_dense(P, q, G, h, abstol=1e-7, reltol=1e-6, feastol=1e-7, maxiters=100):

@@ -168,6 +168,22 @@ def test_c_ipm_baseline_matches_golden(golden_dir):
     assert st == 0 and abs(0.5 * x @ d["P"] @ x + d["q"] @ x - float(d["objective"])) <= 1e-7 * abs(float(d["objective"]))
 
 
+def test_c_activeset_baseline_matches_golden(golden_dir):
+    """oracle/qp_activeset.c (the like-for-like CPU line: the GPU's algorithm on the host) lands on the certified optimum."""
+    from oracle import cpu_baseline as cb
+    try:
+        cb.load()
+    except RuntimeError:
+        pytest.skip("oracle/libqpipm.so not built")
+    for cfg in (1, 2, 3):
+        g = np.load(os.path.join(golden_dir, f"mpc_cfg{cfg}.npz"))
+        N = int(g["N"]); lb = np.tile(g["u_min"], N); ub = np.tile(g["u_max"], N)
+        U, st, bad, _ = cb.solve_batch_box_activeset(g["H"], g["F"], g["f0"], lb, ub, g["x0"], nthreads=2)
+        assert bad == 0 and (st >= 0).all()
+        assert (np.abs(U - g["U"]).max(1) / np.abs(g["U"]).max(1)).max() <= 1e-8
+        assert ((U >= ub - 1e-13) | (U <= lb + 1e-13)).sum(1).tolist() == (g["lam"] != 0).sum(1).tolist()
+
+
 def test_sweep_fixtures_are_certified_and_reproducible():
     """tests/golden/sweep_*.npz: QPs from the reference's sequential loops run end to end.  Every stored optimum
     carries a KKT certificate; re-solving a few reproduces it (the oracle is deterministic)."""
