@@ -490,8 +490,8 @@ class RowsWorkload:
         self.x0 = torch.as_tensor(prob["x0"][lo:hi], device=dev).contiguous()
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
-        pl.setup()
-        pl.solve(self.x0[:1])           # the Gram set-up runs with the first solve
+        pl.setup()                      # assemble + the rows and their dual Hessian (mpcqp_factor, general mode)
+        pl.solve(self.x0[:1])
         torch.cuda.synchronize(dev)
         self.setup_ms = (time.perf_counter() - t0) * 1e3
         self.units_per_step = self.global_batch
@@ -505,7 +505,7 @@ class RowsWorkload:
         args, ranks, torch, pl, prob = self.args, self.ranks, self.torch, self.pl, self.prob
         timed = device_timer(torch, ranks.dev)
         info = pl.info
-        n, m = pl.n, int(pl._gen["G"].shape[0])
+        n, m = pl.n, int(pl.general_info()["m"])
         steps = info.polish_steps.double()
         k_mean, k_max = float(steps.mean().item()), int(steps.max().item())
         solve_ms = timed(lambda: pl.solve(self.x0), 10)
@@ -519,7 +519,7 @@ class RowsWorkload:
         config = {"workload": f"configs[4]: long-horizon MPC nx={prob['nx']} nu={prob['nu']} N={prob['N']} (n={n}, {m} one-sided "
                               f"rows: input box + state box + polytope), {self.global_batch} x0 over {ranks.world} GPU(s), "
                               "shared model",
-                  "batch_per_gpu": self.B, "global_batch": self.global_batch, "path": pl.general_path,
+                  "batch_per_gpu": self.B, "global_batch": self.global_batch, "path": pl.general_info()["kernel"],
                   "parallelism": f"dp{ranks.world} (independent shards)", "setup_ms": self.setup_ms,
                   "active_set_steps_mean": k_mean, "active_set_steps_max": k_max,
                   "solved_fraction": float((info.status == 0).float().mean().item()), "batch_latency_ms": solve_ms,
@@ -531,9 +531,7 @@ class RowsWorkload:
         import numpy as np
         from oracle import cpu_baseline as cb
         pl = self.pl
-        g = pl._gen
-        H = g["H"].cpu().numpy(); F = g["F"].cpu().numpy(); f0 = g["f0"].cpu().numpy()
-        G = g["G"].cpu().numpy(); E = g["E"].cpu().numpy(); h0 = g["h0"].cpu().numpy()
+        H, F, f0, G, E, h0 = (pl.get(k).cpu().numpy() for k in ("H", "F", "f0", "G", "E", "h0"))
         x0 = self.prob["x0"]
         from concurrent.futures import ThreadPoolExecutor
         cores = _host_cores()

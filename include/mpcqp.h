@@ -116,6 +116,26 @@ int mpcqp_set_cost(mpcqp_handle h, const double* Q, const double* R, const doubl
 /* u_min, u_max: (nu) applied at every stage (per_stage = 0) or (N, nu) (per_stage = 1). */
 int mpcqp_set_constraints(mpcqp_handle h, const double* u_min, const double* u_max, int per_stage);
 
+/* State box x_min <= x_k <= x_max and polytopic rows c_min <= C_k x_k <= c_max on x_1..x_N -- the reference's state rows
+ * (rows of the prediction matrix, LaunchPlannerQPFormulation.py:109-118) and friction-pyramid rows
+ * (Launch3DPlanner.py:134-156).  x_min, x_max: (N, nx) or both NULL; C: (N, nc, nx) with c_min, c_max (N, nc), or NULL.
+ * +-infinity opens a side: rows with an infinite bound are dropped on the device, as HelperFuncs.removeNullConstraints
+ * (HelperFuncs.py:41-54) drops rows that constrain nothing.  With any of them set -- or with N*nu > 128 -- mpcqp_factor
+ * builds the condensed rows [I; -I; Gamma; -Gamma; C Gamma; -C Gamma] U <= h0 - E x0 and sets up the constraint-space
+ * kernel (mpcqp_rows_*) or, when its m x m dual Hessian exceeds the memory limit, the general dense kernel
+ * (mpcqp_dense_shared_*); mpcqp_solve then runs that kernel.  In this mode: shared model only (n_models = 1), no
+ * warm start / shift, mpcqp_factor synchronises, info.lam (if given) holds (batch, m) multipliers of the kept rows
+ * (m from mpcqp_general_rows; mpcqp_get 13 / 14 / 15 return G (m,n), E (m,nx), h0 (m)), status 3 = infeasible,
+ * 4 = numerical failure. */
+int mpcqp_set_state_constraints(mpcqp_handle h, const double* x_min, const double* x_max, const double* C,
+                                const double* c_min, const double* c_max, int nc);
+/* path: 0 = constraint-space kernel when rows beyond the input box exist and its workspace fits (default), 1 = always
+ * the general dense kernel, 2 = constraint-space kernel even for a plain input box; mem_limit_bytes: workspace the
+ * constraint-space kernel may take (0 keeps the current value; default 32 GiB). */
+int mpcqp_set_general_opts(mpcqp_handle h, int path, long mem_limit_bytes);
+/* rows kept by the last mpcqp_factor in the general mode (0: the box kernels are in use) */
+int mpcqp_general_rows(mpcqp_handle h, int* m, int* uses_rows_kernel);
+
 /* One model per instance (dims.n_models = batch > 1; e.g. an LTV re-linearisation about each instance's own
  * trajectory): x_ref, u_ref and the bounds may then differ per model too.  Strides are in doubles between
  * consecutive models, 0 = shared by all (the default).  In this regime there is no shared factor, so
@@ -150,7 +170,8 @@ int mpcqp_recenter(mpcqp_handle h, void* stream);
  *        10 z (batch,n) scaled  11 w (batch,n) scaled
  *        12 diagnostics of the last solve (96 values): [0] instances handed to the second active-set pass (routed by the
  *           cold-start ordering + overflow of the first), [1] handed on to the 64-row pass, [2] instances the first pass
- *           took, [3] handed to the any-size pass, [16..48) histogram of the cold-start keys                          */
+ *           took, [3] handed to the any-size pass, [16..48) histogram of the cold-start keys
+ *        13 G (m,n)  14 E (m,nx)  15 h0 (m): the condensed rows of the general-constraint mode                       */
 int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, void* stream);
 
 /* -- dense QP: the reference's literal call  cvxopt.solvers.qp(P, q, G, h[, A, b]) ---------------------

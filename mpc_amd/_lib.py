@@ -50,6 +50,9 @@ SYMBOLS = [
     ("mpcqp_set_cost", C.c_int, [C.c_void_p] + [C.c_void_p] * 5),
     ("mpcqp_set_constraints", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
     ("mpcqp_set_strides", C.c_int, [C.c_void_p, C.c_long, C.c_long, C.c_long]),
+    ("mpcqp_set_state_constraints", C.c_int, [C.c_void_p] * 6 + [C.c_int]),
+    ("mpcqp_set_general_opts", C.c_int, [C.c_void_p, C.c_int, C.c_long]),
+    ("mpcqp_general_rows", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("mpcqp_assemble", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_factor", C.c_int, [C.c_void_p, C.POINTER(FactorOpts), C.c_void_p]),
     ("mpcqp_solve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Info),

@@ -138,6 +138,7 @@ int mpcqp_destroy(mpcqp_handle h) {
                     h->Ku1, h->Cq, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev, h->mflag,
                     h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws, h->hbuf1, h->hbuf2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    general_free(h);
     delete h;
     return MPCQP_OK;
 }
@@ -190,9 +191,11 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->assembled) { h->err = "factor: assemble first"; return MPCQP_ESTATE; }
     if (!h->umin) { h->err = "factor: set_constraints first"; return MPCQP_ESTATE; }
-    if (!admm_shared_box_supported(h->NT, h->S)) { h->err = "factor: N*nu > 128 is not implemented in this build"; return MPCQP_ENOTIMPL; }
     HIPCHK(h, hipSetDevice(h->dev));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // state-box / polytopic rows, or more inputs than the box kernels hold: the general-constraint path (general.hip)
+    if (h->g_xmin || h->g_C || h->g_path == 2 || !admm_shared_box_supported(h->NT, h->S)) return factor_general(h, st);
+    if (h->general) general_free(h);
     if (h->dims.n_models > 1) TRY(launch_factor_batch(h, st));      // one model per instance: active-set path only
     else TRY(launch_factor(h, opts ? opts->rho : 0.0, st));
     if (opts && opts->no_sync && (h->dims.n_models > 1 || opts->rho > 0.0)) {
@@ -224,6 +227,10 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
     if (!(o.alpha > 0.0 && o.alpha < 2.0) || o.max_iter < 0) { h->err = "solve: alpha must be in (0,2), max_iter >= 0"; return MPCQP_EINVAL; }
     HIPCHK(h, hipSetDevice(h->dev));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (h->general) {
+        if (o.warm_start) { h->err = "solve: the general-constraint path keeps no warm-start state"; return MPCQP_EINVAL; }
+        return solve_general(h, x0, batch, U, info, st);
+    }
     TRY(ensure_batch(h, batch));
     if (o.warm_start && h->has_state && batch != h->Blast) { h->err = "solve: warm start needs the same batch as the previous solve"; return MPCQP_EINVAL; }
     if (h->dims.n_models == 1 && (o.stages & 2) && !(o.stages & 1) && !(h->has_state && batch == h->Blast)) {
@@ -286,6 +293,12 @@ int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, v
                                static_cast<hipStream_t>(stream), which == 10 ? h->z : h->w, out, h->Blast, h->NP, h->n);
             HIPCHK(h, hipGetLastError());
             return MPCQP_OK;
+        }
+        case 13: case 14: case 15: {
+            if (!h->general) { h->err = "get: no general-constraint rows (set_state_constraints + factor first)"; return MPCQP_ESTATE; }
+            src = which == 13 ? h->gG : (which == 14 ? h->gE : h->gh0);
+            len = which == 13 ? (size_t)h->g_m * n : (which == 14 ? (size_t)h->g_m * nx : (size_t)h->g_m);
+            break;
         }
         case 12: {
             if (!h->has_state) { h->err = "get: no solution state yet"; return MPCQP_ESTATE; }

@@ -53,6 +53,16 @@ struct mpcqp_handle_s {
     int *it_ws = nullptr;                  // [6 Bcap + 96]: iters | need_big | converged | polish queue 1 | queue 2 | counters, buckets (96) | cold-start order
     double *rp_ws = nullptr, *rd_ws = nullptr;
     double *hbuf1 = nullptr, *hbuf2 = nullptr;   // hand-over of the working state between active-set passes: [Bcap][16*16+66], [Bcap/4][32*32+130]
+    // general-constraint path (general.hip): state-box / polytopic rows, or N*nu > 128
+    const double *g_xmin = nullptr, *g_xmax = nullptr, *g_C = nullptr, *g_cmin = nullptr, *g_cmax = nullptr;   // caller-owned
+    int g_nc = 0;
+    int g_path = 0;                         // 0 auto | 1 dense kernel | 2 constraint-space kernel
+    long g_mem_limit = 32L << 30;           // bytes of shared workspace (the m x m dual Hessian) the constraint-space kernel may take
+    bool general = false, g_rows = false;   // the last factorisation took the general path / the constraint-space kernel
+    int g_m = 0, g_bcap = 0, g_dcap = 0; long g_per = 0;
+    double *gG = nullptr, *gE = nullptr, *gh0 = nullptr;        // (m, n), (m, nx), (m): rows G U <= h0 - E x0, infinite bounds dropped
+    double *g_shared = nullptr, *g_inst = nullptr, *g_q = nullptr, *g_hh = nullptr, *g_z = nullptr, *g_obj = nullptr, *g_dws = nullptr;
+    int *g_iws = nullptr, *g_st = nullptr, *g_it = nullptr, *g_diws = nullptr;
     bool assembled = false, factored = false, has_state = false;
     std::string err;
 };
@@ -79,3 +89,6 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
                       const mpcqp_solve_opts& o, hipStream_t st);
 int launch_shift(mpcqp_handle h, hipStream_t st);
 bool admm_shared_box_supported(int NT, int S);
+int factor_general(mpcqp_handle h, hipStream_t st);
+int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st);
+void general_free(mpcqp_handle h);

@@ -552,6 +552,12 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
 
 }  // namespace
 
+// general.hip: C (M, N) = alpha A (M, K) B (N, K)' + bias[j]
+int gemm_nt_bias(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int M, int N, int K, double alpha,
+                 const double* bias, hipStream_t st) {
+    return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, alpha, 0.0, st, bias);
+}
+
 extern "C" {
 
 long mpcqp_rows_workspace(int n, int m, long* per_instance) {

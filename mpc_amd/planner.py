@@ -60,13 +60,32 @@ class Planner:
         self.rho = None
         self.info = None
         self._general = None         # state-box / polytopic rows, if any
-        self.general_path = "rows"   # "rows": Gram / constraint-space kernel; "dense": the general dense kernel
-        self.rows_mem_limit = 32 << 30   # bytes of shared workspace (Gram matrix) above which "rows" falls back to "dense"
-        self._gen = None             # their condensed form (G, E, h0), built by setup()
+        self._general_path = "rows"  # "rows": Gram / constraint-space kernel; "dense": the general dense kernel
+        self._rows_mem_limit = 32 << 30  # bytes of shared workspace (Gram matrix) above which "rows" falls back to "dense"
+        self._gen_m, self._gen_kernel = 0, None     # rows and kernel of the general-constraint mode, set by setup()
         self.no_sync = False         # True: set-up calls never wait for the device (closed loops)
         self.check_inputs = True     # False: skip the host-side sanity checks that synchronise (u_min <= u_max)
         self.opts = _lib.SolveOpts()
         self._lib.mpcqp_default_solve_opts(C.byref(self.opts))
+
+    # kernel choice of the general-constraint mode: a change takes effect with the next set-up
+    @property
+    def general_path(self):
+        return self._general_path
+
+    @general_path.setter
+    def general_path(self, v):
+        if v not in ("rows", "dense"):
+            raise ValueError("general_path must be 'rows' or 'dense'")
+        self._general_path, self._dirty = v, True
+
+    @property
+    def rows_mem_limit(self):
+        return self._rows_mem_limit
+
+    @rows_mem_limit.setter
+    def rows_mem_limit(self, v):
+        self._rows_mem_limit, self._dirty = int(v), True
 
     # ---- lifetime ------------------------------------------------------------------
     def _create(self, n_models, time_varying):
@@ -181,6 +200,10 @@ class Planner:
     def _push_constraints(self):
         k = self._keep
         self._check(self._lib.mpcqp_set_constraints(self._h, _ptr(k["u_min"]), _ptr(k["u_max"]), k["per_stage"]))
+        g = self._general or {}
+        self._check(self._lib.mpcqp_set_state_constraints(
+            self._h, _ptr(g.get("x_min")), _ptr(g.get("x_max")), _ptr(g.get("C")), _ptr(g.get("c_min")), _ptr(g.get("c_max")),
+            int(g["C"].shape[1]) if "C" in g else 0))
 
     def set_constraints(self, u_min, u_max, x_min=None, x_max=None, C=None, c_min=None, c_max=None):
         """Input box u_min <= u_k <= u_max, (nu,) or (N,nu).  State box x_min <= x_k <= x_max and polytopic rows
@@ -246,105 +269,29 @@ class Planner:
         if self._h is None or "Q" not in self._keep or "u_min" not in self._keep:
             raise RuntimeError("set_model, set_cost and set_constraints must be called before solve")
         self._check(self._lib.mpcqp_assemble(self._h, self._stream()))
-        if self._general is not None or (self._n_models == 1 and self.n > 128):
-            # general rows (or a horizon beyond the ADMM kernel's n <= 128): the dense kernel scales and factors per QP
-            self._gen = self._condense_rows()
-            self.rho = None
-            self._dirty = False
-            return self
-        self._gen = None
-        no_sync = bool(self.no_sync and (self._n_models > 1 or rho))
+        # state-box / polytopic rows (or N*nu > 128) are routed inside the library: mpcqp_factor builds the condensed rows on the
+        # device and sets up the constraint-space or the dense kernel (general.hip)
+        self._check(self._lib.mpcqp_set_general_opts(self._h, {"rows": 0, "dense": 1}[self.general_path],
+                                                     int(self.rows_mem_limit)))
+        general = self._general is not None or (self._n_models == 1 and self.n > 128)
+        no_sync = bool(self.no_sync and (self._n_models > 1 or rho)) and not general
         fo = _lib.FactorOpts(float(rho) if rho else 0.0, int(no_sync), int(bool(keep_state)))
         self._check(self._lib.mpcqp_factor(self._h, C.byref(fo), self._stream()))
-        self.rho = (1.0 if self._n_models > 1 else float(rho)) if no_sync else float(self.get("rho")[0])
+        m = C.c_int(0); rows = C.c_int(0)
+        self._check(self._lib.mpcqp_general_rows(self._h, C.byref(m), C.byref(rows)))
+        self._gen_m = int(m.value)
+        self._gen_kernel = None if m.value == 0 else ("rows" if rows.value else "dense")
+        if self._gen_m:
+            self.rho = None
+        else:
+            self.rho = (1.0 if self._n_models > 1 else float(rho)) if no_sync else float(self.get("rho")[0])
         self._dirty = False
         return self
 
-    def _condense_rows(self):
-        """One-sided rows G U <= h0 - E x0 of the condensed problem (rows with an infinite bound are dropped, as
-        HelperFuncs.removeNullConstraints does for the reference's stacked constraints)."""
-        if self._n_models != 1:
-            raise NotImplementedError("state / polytopic rows with one model per instance are not implemented")
-        n, nx, N = self.n, self.nx, self.N
-        dev = self.device
-        Gam = self.get("Gamma"); Phi = self.get("Phi")          # (N nx, n), (N nx, nx): x_k = Gam_k U + Phi_k x0
-        k = self._keep
-        ub = k["u_max"] if k["per_stage"] else k["u_max"].repeat(N)
-        lb = k["u_min"] if k["per_stage"] else k["u_min"].repeat(N)
-        I = torch.eye(n, dtype=torch.float64, device=dev)
-        Z = torch.zeros((n, nx), dtype=torch.float64, device=dev)
-        rows = [(I, Z, ub), (-I, Z, -lb)]
-        g = self._general or {}
-        if "x_max" in g:
-            rows += [(Gam, Phi, g["x_max"].reshape(-1)), (-Gam, -Phi, -g["x_min"].reshape(-1))]
-        if "C" in g:
-            Cm = g["C"]                                            # (N, nc, nx)
-            CG = torch.bmm(Cm, Gam.reshape(N, nx, n)).reshape(-1, n)
-            CP = torch.bmm(Cm, Phi.reshape(N, nx, nx)).reshape(-1, nx)
-            rows += [(CG, CP, g["c_max"].reshape(-1)), (-CG, -CP, -g["c_min"].reshape(-1))]
-        G = torch.cat([r[0] for r in rows]); E = torch.cat([r[1] for r in rows]); h0 = torch.cat([r[2] for r in rows])
-        keep = torch.isfinite(h0)
-        return dict(G=G[keep].contiguous(), E=E[keep].contiguous(), h0=h0[keep].contiguous(),
-                    H=self.get("H"), F=self.get("F"), f0=self.get("f0"))
-
-    def _solve_general(self, x0, want_multipliers):
-        gen = self._gen
-        dev = self.device
-        lib = self._lib
-        B, n, m = x0.shape[0], self.n, gen["G"].shape[0]
-        x = torch.empty((B, n), dtype=torch.float64, device=dev)
-        z = torch.empty((B, max(m, 1)), dtype=torch.float64, device=dev)      # both kernels zero the inactive entries
-        obj = torch.empty(B, dtype=torch.float64, device=dev)
-        st = torch.empty(B, dtype=torch.int32, device=dev)
-        iters = torch.empty(B, dtype=torch.int32, device=dev)
-        per = C.c_long(0)
-        ns = lib.mpcqp_rows_workspace(n, m, C.byref(per)) if m > 0 else 0
-        if self.general_path == "rows" and self._general is not None and m > 0 and 8 * ns <= self.rows_mem_limit:
-            # constraint-space path: Gram matrix of the rows once per model, then (k+1) of its rows per active-set step
-            if gen.get("rows_shared") is None:
-                gen["rows_shared"] = torch.empty(ns, dtype=torch.float64, device=dev)
-                iws = torch.empty(max(n, 1), dtype=torch.int32, device=dev)
-                rc = lib.mpcqp_rows_setup(dev.index or 0, n, m, _ptr(gen["H"]), _ptr(gen["G"]), _ptr(gen["rows_shared"]),
-                                          _ptr(iws), self._stream())
-                if rc != _lib.OK:
-                    raise RuntimeError(f"mpcqp_rows_setup failed with code {rc}")
-            if gen.get("rows_inst") is None or gen["rows_batch"] < B:
-                gen["rows_inst"] = torch.empty(B * per.value, dtype=torch.float64, device=dev)
-                gen["rows_batch"] = B
-            x0 = x0.contiguous()
-            rc = lib.mpcqp_rows_solve_mpc(dev.index or 0, B, n, m, self.nx, _ptr(x0), _ptr(gen["F"]), _ptr(gen["f0"]),
-                                          _ptr(gen["E"]), _ptr(gen["h0"]), _ptr(x), _ptr(z), _ptr(obj), _ptr(st), _ptr(iters),
-                                          _ptr(gen["rows_shared"]), _ptr(gen["rows_inst"]), self._stream())
-            if rc != _lib.OK:
-                raise RuntimeError(f"mpcqp_rows_solve_mpc failed with code {rc}")
-            return self._general_info(x, z, obj, st, iters, m, want_multipliers)
-        q = torch.addmm(gen["f0"].unsqueeze(0), x0, gen["F"].t()).contiguous()        # q = F x0 + f0
-        h = (gen["h0"].unsqueeze(0) - x0 @ gen["E"].t()).contiguous()                 # h = h0 - E x0
-        ni = C.c_long(0)
-        nd = lib.mpcqp_dense_workspace(n, m, 0, C.byref(ni))
-        if gen.get("ws") is None or gen["ws_batch"] < B:        # shared set-up: once per model (and per larger batch)
-            gen["ws"] = torch.empty(B * nd, dtype=torch.float64, device=dev)
-            gen["iws"] = torch.empty(B * ni.value, dtype=torch.int32, device=dev)
-            gen["ws_batch"] = B
-            rc = lib.mpcqp_dense_shared_setup(dev.index or 0, n, m, 0, _ptr(gen["H"]), _ptr(gen["G"]), C.c_void_p(0),
-                                              _ptr(gen["ws"]), _ptr(gen["iws"]), self._stream())
-            if rc != _lib.OK:
-                raise RuntimeError(f"mpcqp_dense_shared_setup failed with code {rc}")
-        rc = lib.mpcqp_dense_shared_solve(dev.index or 0, B, n, m, 0, _ptr(q), _ptr(h), C.c_void_p(0), _ptr(x), _ptr(z),
-                                          C.c_void_p(0), _ptr(obj), _ptr(st), _ptr(iters), _ptr(gen["ws"]), _ptr(gen["iws"]),
-                                          self._stream())
-        if rc != _lib.OK:
-            raise RuntimeError(f"mpcqp_dense_shared_solve failed with code {rc}")
-        return self._general_info(x, z, obj, st, iters, m, want_multipliers)
-
-    def _general_info(self, x, z, obj, st, iters, m, want_multipliers):
-        # dense status 0 optimal | 1 step cap | 2 infeasible | 3 numerical  ->  MPCQP_SOLVED | MPCQP_MAX_ITER | 3 | 4
-        B = x.shape[0]
-        status = torch.where(st == 0, torch.zeros_like(st), st + 1)
-        self.info = SimpleNamespace(iters=torch.zeros(B, dtype=torch.int32, device=self.device), status=status,
-                                    obj=obj, prim_res=None, dual_res=None,
-                                    polish_steps=iters % 1000, lam=z[:, :m] if want_multipliers else None)
-        return x.reshape(B, self.N, self.nu)
+    def general_info(self):
+        """Rows and kernel of the general-constraint mode after setup(): {'m': kept rows (0 = box kernels), 'kernel':
+        'rows' | 'dense' | None}; the rows themselves are get('G'), get('E'), get('h0')."""
+        return {"m": getattr(self, "_gen_m", 0), "kernel": getattr(self, "_gen_kernel", None)}
 
     def solve(self, x0, warm_start=None, want_multipliers=False, **opts):
         """x0 (B,nx) -> U (B,N,nu) on the device; per-instance diagnostics in ``self.info``
@@ -359,9 +306,8 @@ class Planner:
             x0 = x0.reshape(1, -1)
         if x0.dim() != 2 or x0.shape[1] != self.nx:
             raise ValueError(f"x0: expected (B, {self.nx}), got {tuple(x0.shape)}")
-        if self._gen is not None:
-            return self._solve_general(x0, want_multipliers)
         B = x0.shape[0]
+        gm = getattr(self, "_gen_m", 0)
         o = _lib.SolveOpts.from_buffer_copy(self.opts)
         for k, v in opts.items():
             if not hasattr(o, k):
@@ -378,7 +324,7 @@ class Planner:
             prim_res=torch.empty(B, dtype=torch.float64, device=dev),
             dual_res=torch.empty(B, dtype=torch.float64, device=dev),
             polish_steps=torch.empty(B, dtype=torch.int32, device=dev),
-            lam=torch.empty((B, self.n), dtype=torch.float64, device=dev) if want_multipliers else None)
+            lam=torch.empty((B, gm if gm else self.n), dtype=torch.float64, device=dev) if want_multipliers else None)
         ci = _lib.Info(*[_ptr(getattr(info, f[0])) for f in _lib.Info._fields_])
         self._check(self._lib.mpcqp_solve(self._h, _ptr(x0), B, _ptr(U), C.byref(ci), C.byref(o), self._stream()))
         self.info = info
@@ -412,12 +358,14 @@ class Planner:
 
     # ---- introspection -------------------------------------------------------------------
     _GET = {"H": 0, "F": 1, "f0": 2, "Gamma": 3, "Phi": 4, "Hs": 5, "M": 6, "Hi": 7, "d": 8, "rho": 9,
-            "z": 10, "w": 11, "queues": 12}
+            "z": 10, "w": 11, "queues": 12, "G": 13, "E": 14, "h0": 15}
 
     def get(self, name, batch=None, model=0):
         n, p, nx = self.n, self.N * self.nx, self.nx
         shapes = {"H": (n, n), "F": (n, nx), "f0": (n,), "Gamma": (p, n), "Phi": (p, nx), "Hs": (n, n),
                   "M": (n, n), "Hi": (n, n), "d": (n,), "rho": (3,), "queues": (96,)}
+        gm = getattr(self, "_gen_m", 0)
+        shapes.update({"G": (gm, n), "E": (gm, nx), "h0": (gm,)})
         if name in ("z", "w"):
             if batch is None:
                 raise ValueError("get('z'|'w') needs batch=")

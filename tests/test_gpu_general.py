@@ -46,7 +46,11 @@ def test_state_and_polytope_rows_match_oracle(N, nx, nu, batch, path):
     H, F, f0 = mo.condense(prob)
     G, E, h0 = _oracle_rows(prob)
     assert pl.info.lam.shape[1] == G.shape[0]
-    assert ("rows_shared" in pl._gen) == (path == "rows")
+    assert pl.general_info() == {"m": G.shape[0], "kernel": path}
+    # the rows the library built and pruned on the device are the restatement's, in the same order
+    assert np.abs(pl.get("G").cpu().numpy() - G).max() <= 1e-12 * max(1.0, np.abs(G).max())
+    assert np.abs(pl.get("E").cpu().numpy() - E).max() <= 1e-12 * max(1.0, np.abs(E).max())
+    assert np.array_equal(pl.get("h0").cpu().numpy(), h0)
     nbind = 0
     for i in range(batch):
         q = F @ prob["x0"][i] + f0; h = h0 - E @ prob["x0"][i]
@@ -76,7 +80,7 @@ def test_full_horizon_config5_kkt_certificate():
                        C=prob["C"], c_min=prob["c_min"], c_max=prob["c_max"])
     U = pl.solve(prob["x0"], want_multipliers=True).cpu().numpy().reshape(batch, -1)
     st = pl.info.status.cpu().numpy(); z = pl.info.lam.cpu().numpy(); obj = pl.info.obj.cpu().numpy()
-    assert "rows_shared" in pl._gen                      # the default: the constraint-space kernel
+    assert pl.general_info()["kernel"] == "rows"         # the default: the constraint-space kernel
     # the general dense kernel on the same data lands on the same vertex
     pl.general_path = "dense"
     Ud = pl.solve(prob["x0"]).cpu().numpy().reshape(batch, -1)

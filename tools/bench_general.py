@@ -20,6 +20,6 @@ t0 = time.perf_counter(); pl.setup(); torch.cuda.synchronize(); t_setup = time.p
 t0 = time.perf_counter(); U = pl.solve(x0); torch.cuda.synchronize(); t_first = time.perf_counter() - t0
 t0 = time.perf_counter(); U = pl.solve(x0); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 st = pl.info.status
-print(json.dumps({"workload": f"long-horizon MPC nx={a.nx} nu={a.nu} N={a.N}: n={a.N*a.nu}, rows={pl._gen['G'].shape[0]}", "batch": a.batch,
+print(json.dumps({"workload": f"long-horizon MPC nx={a.nx} nu={a.nu} N={a.N}: n={a.N*a.nu}, rows={pl.general_info()['m']}", "batch": a.batch,
                   "path": a.path, "setup_ms": t_setup * 1e3, "first_solve_ms": t_first * 1e3, "solve_ms": dt * 1e3, "solves_per_s": a.batch / dt, "solved_fraction": float((st == 0).float().mean()),
                   "active_set_steps_mean": float(pl.info.polish_steps.float().mean()), "active_set_steps_max": int(pl.info.polish_steps.max()), "status_hist": torch.bincount(st).tolist()}))
