@@ -14,7 +14,7 @@ torch.distributed.run, BEFORE it touches the GPU -- relays rank 0's JSON line an
 driver's own torch.distributed.run the ranks already exist and it just runs as one of them.
 Scaling (BASELINE.json configs[2]): "strong" (default) = the 65,536 x0 are SPLIT over the ranks, rank r
 solves rows shard_range(65536, r, N); "weak" = 65,536 per GPU.  No data-path collective: instances are independent.  Every
-step ends with the all-reduce(MIN) of the all-solved flag; the all-gather of the solutions is timed separately
+step ends with the all-reduce of the convergence flag (MAX of the worst per-instance status, 0 = all solved); the all-gather of the solutions is timed separately
 (config.allgather_ms).
 
 Other workloads (same JSON schema, `config.workload` names them): --config 2 cart-pole 4,096 instances; --config 4
@@ -152,7 +152,8 @@ class Ranks:
         self.local = local % ndev
         torch.cuda.set_device(self.local)
         self.dev = torch.device(f"cuda:{self.local}")
-        if self.world > 1:
+        # MPC_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL calls on a one-GPU box)
+        if self.world > 1 or (os.environ.get("MPC_BENCH_FORCE_DIST") and "RANK" in os.environ):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -164,8 +165,8 @@ class Ranks:
             self.dist = dist
         self.cdev = self.dev if self.backend in (None, "nccl") else torch.device("cpu")
         self._bar = torch.zeros(1, dtype=torch.int32, device=self.cdev)
-        self._flags = [torch.zeros(1, dtype=torch.int32, device=self.cdev) for _ in range(2)]
-        self._pending = None
+        self._flags = [torch.zeros(1, dtype=torch.int32, device=self.cdev) for _ in range(8)]
+        self._pending = [None] * 8
         self._n = 0
         self.all_ok = True
 
@@ -177,25 +178,36 @@ class Ranks:
             if self.cdev.type == "cuda":
                 self.torch.cuda.synchronize(self.dev)
 
-    def flag_allreduce(self, ok_dev):
-        """all-reduce(MIN) of this step's all-solved flag; the reduce of step i is in flight while step i+1 computes
-        (two buffers); drain() ends the timed region, so every collective is inside it."""
+    def flag_allreduce(self, status_dev):
+        """all-reduce(MAX) of this step's worst per-instance status (0 = every instance of every rank solved: the
+        convergence flag).  The reduce of step i is in flight while the next steps compute: a ring of 8 flag buffers, and a
+        buffer is only written again once the collective that read it has finished (by then it long has: waiting for the
+        reduce of the step just before would stall the compute stream behind a collective that cannot get a CU while the
+        solve kernels fill the device).  drain() ends the timed region, so every collective is inside it."""
         if self.dist is None:
             return
-        f = self._flags[self._n & 1]
+        j = self._n & 7
         self._n += 1
-        # RCCL: device-to-device copy, ordered on the compute stream, which the collective's stream waits for.
-        # gloo: a BLOCKING copy to the host tensor -- it must have landed before the collective reads it.
-        f.copy_(ok_dev)
-        self.drain()
-        self._pending = (self.dist.all_reduce(f, op=self.dist.ReduceOp.MIN, async_op=True), f)
+        if self._pending[j] is not None:
+            self._pending[j].wait()
+        f = self._flags[j]
+        if self.cdev.type == "cuda":
+            # RCCL: the reduction kernel writes the flag buffer itself, on the compute stream, which the collective's stream waits for
+            self.torch.amax(status_dev, dim=0, keepdim=True, out=f)
+        else:
+            # gloo: a BLOCKING copy to the host tensor -- it must have landed before the collective reads it
+            f.copy_(self.torch.amax(status_dev, dim=0, keepdim=True))
+        self._pending[j] = self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX, async_op=True)
 
     def drain(self):
-        if self._pending is not None:
-            work, f = self._pending
-            work.wait()
-            self._pending = None
-            self._last_flag = f
+        for j, w in enumerate(self._pending):
+            if w is not None:
+                w.wait()
+                self._pending[j] = None
+        if self.dist is not None and self._n:
+            if self.cdev.type == "cuda":
+                self.torch.cuda.synchronize(self.dev)
+            self.all_ok = self.all_ok and all(int(f.item()) == 0 for f in self._flags[:min(self._n, 8)])
 
     def max_over_ranks(self, seconds):
         if self.dist is None:
@@ -258,15 +270,18 @@ class BoxWorkload:
         self.x0_all = torch.as_tensor(prob["x0"], device=dev)
         self.x0 = self.x0_all[lo:hi].contiguous()
         self.opts = {} if args.max_iter is None else {"max_iter": args.max_iter}
+        pl.reuse_outputs = True
         self.U = None
         self.units_per_step = self.global_batch
         self.name = {2: "configs[1]: cart-pole linearised MPC nx=4 nu=1 N=50 (n=50 box-constrained QP)",
                      3: "configs[2]: quadrotor hover MPC nx=12 nu=4 N=30 (n=120 box-constrained QP)"}[cfg]
 
     def step(self):
+        # reuse_outputs: the same output buffers every step (an eager call otherwise spends more host time on small
+        # allocations than the device needs for a 1/8 shard); the convergence flag is one reduction kernel
         self.U = self.pl.solve(self.x0, **self.opts)
         if self.ranks.dist is not None:
-            self.ranks.flag_allreduce((self.pl.info.status == 0).all().to(self.torch.int32).reshape(1))
+            self.ranks.flag_allreduce(self.pl.info.status)
 
     def report(self, dt):
         args, ranks, torch, pl, prob = self.args, self.ranks, self.torch, self.pl, self.prob
@@ -344,7 +359,7 @@ class BoxWorkload:
                   "p50_batch_latency_ms": p50_ms, "p99_batch_latency_ms": p99_ms, "mean_batch_latency_ms": both_ms,
                   "admm_kernel_ms": admm_ms, "polish_kernels_ms": max(both_ms - admm_ms, 0.0),
                   "first_pass_ms": pass_a_ms, "cold_order_ms": order_ms,
-                  "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if ranks.world > 1 else "none",
+                  "collectives_in_step": "all_reduce(MAX) of the worst status (0 = all solved)" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend, "allgather_ms": allgather_ms, "shard_sweep_ms": sweep,
                   "hbm_GBps_compulsory": B * (8 * prob["nx"] + 8 * n + 16 + 4 * 8 * n) / (both_ms * 1e-3) / 1e9}
         return config, roofline
@@ -393,7 +408,7 @@ class LtvWorkload:
         self.x = self.loop.model.step(self.x, u0)
         self.nsteps += 1
         if self.ranks.dist is not None:
-            self.ranks.flag_allreduce((self.loop.pl.info.status == 0).all().to(self.torch.int32).reshape(1))
+            self.ranks.flag_allreduce(self.loop.pl.info.status)
 
     def report(self, dt):
         import ctypes as C
@@ -430,7 +445,7 @@ class LtvWorkload:
                   "ms_per_closed_loop_step": dt / args.steps * 1e3, "assemble_ms": asm_ms, "factor_ms": fac_ms,
                   "active_set_steps_mean_last": st_mean, "solved_fraction_last": solved,
                   "final_abs_y_max": float(self.x[:, 1].abs().max().item()),
-                  "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if ranks.world > 1 else "none",
+                  "collectives_in_step": "all_reduce(MAX) of the worst status (0 = all solved)" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend}
         return config, roofline
 
@@ -488,6 +503,7 @@ class RowsWorkload:
         pl.set_constraints(prob["u_min"], prob["u_max"], x_min=prob["x_min"], x_max=prob["x_max"], C=prob["C"],
                            c_min=prob["c_min"], c_max=prob["c_max"])
         self.x0 = torch.as_tensor(prob["x0"][lo:hi], device=dev).contiguous()
+        pl.reuse_outputs = True
         torch.cuda.synchronize(dev)
         t0 = time.perf_counter()
         pl.setup()                      # assemble + the rows and their dual Hessian (mpcqp_factor, general mode)
@@ -499,7 +515,7 @@ class RowsWorkload:
     def step(self):
         self.U = self.pl.solve(self.x0)
         if self.ranks.dist is not None:
-            self.ranks.flag_allreduce((self.pl.info.status == 0).all().to(self.torch.int32).reshape(1))
+            self.ranks.flag_allreduce(self.pl.info.status)
 
     def report(self, dt):
         args, ranks, torch, pl, prob = self.args, self.ranks, self.torch, self.pl, self.prob
@@ -523,7 +539,7 @@ class RowsWorkload:
                   "parallelism": f"dp{ranks.world} (independent shards)", "setup_ms": self.setup_ms,
                   "active_set_steps_mean": k_mean, "active_set_steps_max": k_max,
                   "solved_fraction": float((info.status == 0).float().mean().item()), "batch_latency_ms": solve_ms,
-                  "collectives_in_step": "all_reduce(MIN) of the all-solved flag" if ranks.world > 1 else "none",
+                  "collectives_in_step": "all_reduce(MAX) of the worst status (0 = all solved)" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend}
         return config, roofline
 

@@ -54,6 +54,8 @@ class Planner:
         self._lib = _lib.load()
         self._h = None
         self._keep = {}          # tensors whose pointers the handle remembers
+        self.reuse_outputs = False   # True: solve() returns the same U / info buffers for a given batch size on every call
+        self._out = {}               # (they are overwritten by the next solve): no allocations, pre-built argument structs
         self._time_varying = None
         self._n_models = None
         self._dirty = True
@@ -308,6 +310,16 @@ class Planner:
             raise ValueError(f"x0: expected (B, {self.nx}), got {tuple(x0.shape)}")
         B = x0.shape[0]
         gm = getattr(self, "_gen_m", 0)
+        if self.reuse_outputs and not opts and warm_start is None:
+            # serving loops: one set of output buffers and argument structs per batch size (an eager call otherwise spends
+            # ~60 us of host time on ten small allocations and struct set-up, more than the launches themselves)
+            rec = self._out.get((B, gm, want_multipliers))
+            if rec is None:
+                rec = self._out[(B, gm, want_multipliers)] = self._new_outputs(B, gm, want_multipliers)
+            U, info, ci = rec
+            self._check(self._lib.mpcqp_solve(self._h, _ptr(x0), B, _ptr(U), C.byref(ci), C.byref(self.opts), self._stream()))
+            self.info = info
+            return U
         o = _lib.SolveOpts.from_buffer_copy(self.opts)
         for k, v in opts.items():
             if not hasattr(o, k):
@@ -315,6 +327,12 @@ class Planner:
             setattr(o, k, v)
         if warm_start is not None:
             o.warm_start = int(bool(warm_start))
+        U, info, ci = self._new_outputs(B, gm, want_multipliers)
+        self._check(self._lib.mpcqp_solve(self._h, _ptr(x0), B, _ptr(U), C.byref(ci), C.byref(o), self._stream()))
+        self.info = info
+        return U
+
+    def _new_outputs(self, B, gm, want_multipliers):
         dev = self.device
         U = torch.empty((B, self.N, self.nu), dtype=torch.float64, device=dev)
         info = SimpleNamespace(
@@ -326,9 +344,7 @@ class Planner:
             polish_steps=torch.empty(B, dtype=torch.int32, device=dev),
             lam=torch.empty((B, gm if gm else self.n), dtype=torch.float64, device=dev) if want_multipliers else None)
         ci = _lib.Info(*[_ptr(getattr(info, f[0])) for f in _lib.Info._fields_])
-        self._check(self._lib.mpcqp_solve(self._h, _ptr(x0), B, _ptr(U), C.byref(ci), C.byref(o), self._stream()))
-        self.info = info
-        return U
+        return U, info, ci
 
     def shift(self):
         """Receding horizon: move the kept primal/dual state one stage forward (last stage repeated)."""

@@ -214,6 +214,26 @@ def test_no_sync_factor_failure_is_reported_as_status():
         assert (pl.info.status.cpu().numpy() == _lib.SOLVED).all()
 
 
+def test_reuse_outputs_returns_the_same_buffers_with_fresh_results():
+    """Planner.reuse_outputs (serving loops, bench.py): no allocation per call -- same U / info tensors, new contents."""
+    import torch
+    from mpc_amd.configs import make_config
+    from mpc_amd.planner import Planner
+    prob = make_config(3, batch=300, seed=21)
+    pl = Planner(prob["nx"], prob["nu"], prob["N"]).set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+    pl.set_constraints(prob["u_min"], prob["u_max"])
+    xa = torch.as_tensor(prob["x0"], device="cuda:0"); xb = torch.as_tensor(prob["x0"][::-1].copy(), device="cuda:0")
+    Ua = pl.solve(xa).clone(); Ub = pl.solve(xb).clone()          # fresh tensors per call
+    pl.reuse_outputs = True
+    U1 = pl.solve(xa); p1 = U1.data_ptr(); s1 = pl.info.status.data_ptr()
+    assert torch.equal(U1, Ua)
+    U2 = pl.solve(xb)
+    assert U2.data_ptr() == p1 and pl.info.status.data_ptr() == s1 and torch.equal(U2, Ub)
+    assert torch.equal(U2.flip(0), Ua)                             # the reversed batch, instance by instance
+    U3 = pl.solve(xa[:64].contiguous())
+    assert U3.data_ptr() != p1 and torch.equal(U3, Ua[:64])       # another batch size, another set of buffers
+
+
 def test_horizon_beyond_128_inputs_goes_to_the_dense_kernel():
     from mpc_amd.planner import Planner
     from oracle import mpc_oracle as mo
