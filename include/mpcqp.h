@@ -123,7 +123,9 @@ int mpcqp_set_constraints(mpcqp_handle h, const double* u_min, const double* u_m
  * (HelperFuncs.py:41-54) drops rows that constrain nothing.  With any of them set -- or with N*nu > 128 -- mpcqp_factor
  * builds the condensed rows [I; -I; Gamma; -Gamma; C Gamma; -C Gamma] U <= h0 - E x0 and sets up the constraint-space
  * kernel (mpcqp_rows_*) or, when its m x m dual Hessian exceeds the memory limit, the general dense kernel
- * (mpcqp_dense_shared_*); mpcqp_solve then runs that kernel.  In this mode: shared model only (n_models = 1), no
+ * (mpcqp_dense_shared_*); mpcqp_solve then runs that kernel.  With one model per instance (n_models = batch) every
+ * instance is a dense QP of its own -- its Hessian, its rows [..Gamma_b..], q_b = F_b x0_b + f0_b -- solved by the kernel
+ * of mpcqp_solve_dense; the pruning pattern is that of model 0's bounds.  In this mode: no
  * warm start / shift, mpcqp_factor synchronises, info.lam (if given) holds (batch, m) multipliers of the kept rows
  * (m from mpcqp_general_rows; mpcqp_get 13 / 14 / 15 return G (m,n), E (m,nx), h0 (m)), status 3 = infeasible,
  * 4 = numerical failure. */

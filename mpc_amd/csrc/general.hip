@@ -24,15 +24,26 @@ struct RowsParams {
     const double *umin, *umax; int per_stage;
     const double *xmin, *xmax;                  // (N, nx) or nullptr
     const double *C, *cmin, *cmax; int nc;      // (N, nc, nx), (N, nc) or nullptr
-    double *G, *E, *h;                          // (m_full, n), (m_full, nx), (m_full)
+    double *G, *E, *h;                          // (m_full, n), (m_full, nx), (m_full); with `pos`: (m, .) kept rows only
     int n, nx, nu, N, p, xbox, mfull;
+    const int* pos;                             // nullptr: every row at its own index; else row -> kept index or -1 (dropped)
+    int m;                                      // rows kept (with pos)
+    long bnd_stride;                            // one model per instance (blockIdx.z): doubles between the input bounds of models
+    int bounds_only;                            // 1: write only h (pass 1: which rows have a finite bound)
 };
 
 // one thread per (row, column of [G | E]); column 0 also writes the bound
 __global__ __launch_bounds__(256) void build_rows_kernel(RowsParams r) {
     const int row = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
     const int n = r.n, nx = r.nx, p = r.p;
-    if (row >= r.mfull || c >= n + nx) return;
+    if (row >= r.mfull || c >= n + nx || (r.bounds_only && c != 0)) return;
+    const int orow = r.pos ? r.pos[row] : row;          // where the row lands (pruned layout), -1: dropped
+    if (orow < 0) return;
+    const size_t mdl = blockIdx.z;                      // model (0 for a shared model)
+    const int mrows = r.pos ? r.m : r.mfull;
+    r.Gam += mdl * (size_t)p * n; r.Phi += mdl * (size_t)p * nx;
+    r.umin += mdl * r.bnd_stride; r.umax += mdl * r.bnd_stride;
+    r.G += mdl * (size_t)mrows * n; r.E += mdl * (size_t)mrows * nx; r.h += mdl * (size_t)mrows;
     int rr = row;
     double val = 0.0, bound = 0.0;
     const bool isG = c < n;
@@ -66,8 +77,8 @@ __global__ __launch_bounds__(256) void build_rows_kernel(RowsParams r) {
             bound = up ? r.cmax[i] : -r.cmin[i];
         }
     }
-    if (isG) r.G[(size_t)row * n + cc] = val; else r.E[(size_t)row * nx + cc] = val;
-    if (c == 0) r.h[row] = bound;
+    if (!r.bounds_only) { if (isG) r.G[(size_t)orow * n + cc] = val; else r.E[(size_t)orow * nx + cc] = val; }
+    if (c == 0) r.h[orow] = bound;
 }
 
 // pos[i] = rows with a finite bound before row i; *count = their number (one workgroup, chunked scan)
@@ -119,6 +130,27 @@ __global__ void general_info_kernel(const int* st, const int* it, int B, mpcqp_i
     if (info.dual_res) info.dual_res[i] = 0.0;
 }
 
+// one model per instance: q_b = F_b x0_b + f0_b (n), h_b = h0_b - E_b x0_b (m)
+__global__ __launch_bounds__(256) void affine_per_model_kernel(const double* x0, const double* F, const double* f0, const double* E,
+                                                               const double* h0, double* q, double* hh, int n, int m, int nx) {
+    const size_t b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n + m) return;
+    const double* xb = x0 + b * nx;
+    if (i < n) {
+        const double* fr = F + (b * n + i) * nx;
+        double s = f0[b * n + i];
+        for (int c = 0; c < nx; ++c) s += fr[c] * xb[c];
+        q[b * n + i] = s;
+    } else {
+        const int r = i - n;
+        const double* er = E + (b * m + r) * nx;
+        double s = h0[b * m + r];
+        for (int c = 0; c < nx; ++c) s -= er[c] * xb[c];
+        hh[b * m + r] = s;
+    }
+}
+
 template <typename T>
 int grow(mpcqp_handle h, T** p, size_t count) {
     if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -141,25 +173,26 @@ void general_free(mpcqp_handle h) {
 
 // synchronous (it is a set-up call): the number of rows that survive the pruning decides every later allocation
 int factor_general(mpcqp_handle h, hipStream_t st) {
-    if (h->dims.n_models != 1) { h->err = "factor: state / polytopic rows (or N*nu > 128) with one model per instance are not implemented"; return MPCQP_ENOTIMPL; }
-    const int n = h->n, nx = h->dims.nx, p = h->p, N = h->dims.N;
+    const int n = h->n, nx = h->dims.nx, p = h->p, N = h->dims.N, nm = h->dims.n_models;
     const bool xbox = h->g_xmin || h->g_xmax;
     if (xbox && !(h->g_xmin && h->g_xmax)) { h->err = "factor: x_min and x_max must both be given (use +-inf for an open side)"; return MPCQP_EINVAL; }
     const int nc = h->g_C ? h->g_nc : 0;
     const long mfull = 2L * n + (xbox ? 2L * p : 0) + 2L * N * nc;
     general_free(h);
-    double *Gf = nullptr, *Ef = nullptr, *hf = nullptr; int* pos = nullptr;
-    auto cleanup = [&]() { for (void* q : {(void*)Gf, (void*)Ef, (void*)hf, (void*)pos}) if (q) (void)hipFree(q); };
-    int rc = grow(h, &Gf, (size_t)mfull * n);
-    if (rc == MPCQP_OK) rc = grow(h, &Ef, (size_t)mfull * nx);
-    if (rc == MPCQP_OK) rc = grow(h, &hf, (size_t)mfull);
+    double* hf = nullptr; int* pos = nullptr;
+    auto cleanup = [&]() { for (void* q : {(void*)hf, (void*)pos}) if (q) (void)hipFree(q); };
+    int rc = grow(h, &hf, (size_t)mfull);
     if (rc == MPCQP_OK) rc = grow(h, &pos, (size_t)mfull + 1);
     if (rc != MPCQP_OK) { cleanup(); return rc; }
     RowsParams r;
     r.Gam = h->Gam; r.Phi = h->Phi; r.umin = h->umin; r.umax = h->umax; r.per_stage = h->per_stage;
     r.xmin = h->g_xmin; r.xmax = h->g_xmax; r.C = h->g_C; r.cmin = h->g_cmin; r.cmax = h->g_cmax; r.nc = nc;
-    r.G = Gf; r.E = Ef; r.h = hf; r.n = n; r.nx = nx; r.nu = h->dims.nu; r.N = N; r.p = p; r.xbox = xbox ? 1 : 0; r.mfull = (int)mfull;
-    hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)mfull, ceil_div(n + nx, 256)), dim3(256), 0, st, r);
+    r.n = n; r.nx = nx; r.nu = h->dims.nu; r.N = N; r.p = p; r.xbox = xbox ? 1 : 0; r.mfull = (int)mfull;
+    r.bnd_stride = h->bnd_stride;
+    // pass 1: the bounds alone (column 0 of model 0) decide which rows exist -- rows with an infinite bound constrain nothing
+    // (one model per instance: the pattern of model 0 stands for all; a kept row whose own bound is infinite never binds)
+    r.G = nullptr; r.E = nullptr; r.h = hf; r.pos = nullptr; r.m = 0; r.bounds_only = 1;
+    hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)mfull, 1, 1), dim3(256), 0, st, r);
     hipLaunchKernelGGL(finite_scan_kernel, dim3(1), dim3(1024), 0, st, hf, (int)mfull, pos, pos + mfull);
     int m = 0;
     hipError_t e = hipGetLastError();
@@ -167,21 +200,23 @@ int factor_general(mpcqp_handle h, hipStream_t st) {
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (e != hipSuccess) { cleanup(); h->err = std::string("factor (general rows): ") + hipGetErrorString(e); return MPCQP_EHIP; }
     if (m < 1) { cleanup(); h->err = "factor: no finite constraint row is left"; return MPCQP_EINVAL; }
-    rc = grow(h, &h->gG, (size_t)m * n);
-    if (rc == MPCQP_OK) rc = grow(h, &h->gE, (size_t)m * nx);
-    if (rc == MPCQP_OK) rc = grow(h, &h->gh0, (size_t)m);
+    rc = grow(h, &h->gG, (size_t)nm * m * n);
+    if (rc == MPCQP_OK) rc = grow(h, &h->gE, (size_t)nm * m * nx);
+    if (rc == MPCQP_OK) rc = grow(h, &h->gh0, (size_t)nm * m);
     if (rc != MPCQP_OK) { cleanup(); return rc; }
-    hipLaunchKernelGGL(compact_rows_kernel, dim3(ceil_div((int)mfull, 4)), dim3(256), 0, st, Gf, Ef, hf, pos, (int)mfull, n, nx,
-                       h->gG, h->gE, h->gh0);
+    // pass 2: the kept rows of every model, written at their pruned positions
+    r.G = h->gG; r.E = h->gE; r.h = h->gh0; r.pos = pos; r.m = m; r.bounds_only = 0;
+    hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)mfull, ceil_div(n + nx, 256), (unsigned)nm), dim3(256), 0, st, r);
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
     if (e != hipSuccess) { h->err = std::string("factor (general rows): ") + hipGetErrorString(e); return MPCQP_EHIP; }
     h->g_m = m;
-    // constraint-space kernel if its shared workspace (the m x m dual Hessian) fits the limit, else the general dense kernel
+    // shared model: constraint-space kernel if its shared workspace (the m x m dual Hessian) fits the limit, else the general
+    // dense kernel on the shared set-up.  One model per instance: every instance is a dense QP of its own (P_b, G_b).
     long per = 0;
     const long ns = mpcqp_rows_workspace(n, m, &per);
-    h->g_rows = (h->g_path != 1) && (8.0 * (double)ns <= (double)h->g_mem_limit) && (h->g_xmin || h->g_C || h->g_path == 2);
+    h->g_rows = nm == 1 && (h->g_path != 1) && (8.0 * (double)ns <= (double)h->g_mem_limit) && (h->g_xmin || h->g_C || h->g_path == 2);
     if (h->g_rows) {
         TRYG(grow(h, &h->g_shared, (size_t)ns));
         TRYG(grow(h, &h->g_iws, (size_t)n));
@@ -207,7 +242,23 @@ int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcq
     double* z = (info && info->lam) ? info->lam : h->g_z;           // general mode: lam is (batch, m), one value per kept row
     double* obj = (info && info->obj) ? info->obj : h->g_obj;
     int rc;
-    if (h->g_rows) {
+    if (h->dims.n_models > 1) {
+        // one model per instance: B dense QPs with their own Hessian and rows (the kernel of the literal solvers.qp call)
+        if (B != h->dims.n_models) { h->err = "solve: with one model per instance the batch must equal n_models"; return MPCQP_EINVAL; }
+        long ni = 0;
+        const long nd = mpcqp_dense_workspace(n, m, 0, &ni);
+        if (B > h->g_dcap) {
+            TRYG(grow(h, &h->g_dws, (size_t)B * nd));
+            TRYG(grow(h, &h->g_diws, (size_t)B * ni));
+            h->g_dcap = B;
+        }
+        hipLaunchKernelGGL(affine_per_model_kernel, dim3(ceil_div(n + m, 256), (unsigned)B), dim3(256), 0, st, x0, h->F, h->f0, h->gE,
+                           h->gh0, h->g_q, h->g_hh, n, m, nx);
+        HIPCHK(h, hipGetLastError());
+        rc = mpcqp_solve_dense_opts(h->dev, B, n, m, 0, h->H, (long)n * n, h->g_q, n, h->gG, (long)m * n, h->g_hh, m, nullptr, 0,
+                                    nullptr, 0, U, z, nullptr, obj, h->g_st, h->g_it, h->g_dws, h->g_diws, nullptr, st);
+        if (rc != MPCQP_OK) { h->err = "solve: dense path (one model per instance) failed"; return rc; }
+    } else if (h->g_rows) {
         rc = mpcqp_rows_solve_mpc(h->dev, B, n, m, nx, x0, h->F, h->f0, h->gE, h->gh0, U, z, obj, h->g_st, h->g_it, h->g_shared,
                                   h->g_inst, st);
         if (rc != MPCQP_OK) { h->err = "solve: mpcqp_rows_solve_mpc failed"; return rc; }

@@ -127,3 +127,43 @@ def test_rows_path_second_pass_beyond_96_active_rows():
     assert nact.max() > 96 and (nact == nactd).all()
     assert _rel(U, Ud) <= 1e-8
     assert np.abs(obj - objd).max() <= 1e-9 * np.abs(objd).max()
+
+
+def test_state_rows_with_one_model_per_instance_match_oracle():
+    """State-box and polytopic rows when every instance has its OWN time-varying model (the reference's shape: state rows
+    LaunchPlannerQPFormulation.py:109-118 inside a re-linearising loop, CollocationBasedPlanner2D.py:85-365): each instance
+    is a dense QP with its own Hessian and rows, built and solved behind mpcqp_factor / mpcqp_solve."""
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_qp
+    rng = np.random.default_rng(11)
+    nx, nu, N, nb, nc = 3, 2, 6, 7, 2
+    A = 0.9 * np.eye(nx) + 0.15 * rng.standard_normal((nb, N, nx, nx))
+    Bm = rng.standard_normal((nb, N, nx, nu)) * 0.6
+    Q = np.diag([2.0, 1.0, 0.5]); R = 0.2 * np.eye(nu); P = 3.0 * Q
+    u_min = np.array([-0.8, -0.6]); u_max = np.array([0.7, 0.9])
+    x_min = np.array([-0.9, -np.inf, -1.0]); x_max = np.array([0.8, 1.1, np.inf])       # open sides are pruned
+    Cm = rng.standard_normal((nc, nx)); c_min = -1.2 * np.ones(nc); c_max = 1.0 * np.ones(nc)
+    x0 = rng.uniform(-1.2, 1.2, (nb, nx))
+    pl = Planner(nx, nu, N).set_model(A, Bm).set_cost(Q, R, P)
+    pl.set_constraints(u_min, u_max, x_min=x_min, x_max=x_max, C=Cm, c_min=c_min, c_max=c_max)
+    U = pl.solve(x0, want_multipliers=True).cpu().numpy().reshape(nb, -1)
+    st = pl.info.status.cpu().numpy(); obj = pl.info.obj.cpu().numpy()
+    assert pl.general_info()["kernel"] == "dense"
+    n = N * nu
+    nopt = 0
+    for i in range(nb):
+        prob = dict(N=N, nx=nx, nu=nu, A=A[i], B=Bm[i], Q=Q, R=R, P=P, u_min=u_min, u_max=u_max, C=Cm,
+                    x_min=x_min, x_max=x_max, c_min=c_min, c_max=c_max)
+        H, F, f0 = mo.condense(prob)
+        G, E, h0 = _oracle_rows(prob)
+        assert pl.general_info()["m"] == G.shape[0]
+        s = solve_qp(H, F @ x0[i] + f0, G, h0 - E @ x0[i])
+        if s["status"] != "optimal":
+            assert st[i] != 0, i
+            continue
+        nopt += 1
+        assert st[i] == 0, i
+        assert _rel(U[i], s["x"]) <= 1e-6, i
+        assert abs(obj[i] - s["primal objective"]) <= 1e-8 * max(abs(s["primal objective"]), 1e-12), i
+    assert nopt >= 3

@@ -188,10 +188,6 @@ def test_error_conventions():
         pl.set_cost(np.eye(3), np.eye(1))
     with pytest.raises(ValueError):
         pl.set_constraints([-1.0], [1.0], c_min=[0.0])      # polytope bounds without C
-    with pytest.raises(NotImplementedError):              # state rows with one model per instance
-        pm = Planner(2, 1, 5).set_model(np.tile(np.eye(2), (3, 1, 1, 1)), np.ones((3, 1, 2, 1)))
-        pm.set_cost(np.eye(2), np.eye(1)).set_constraints([-1.0], [1.0], x_min=[0, 0])
-        pm.solve(np.zeros((3, 2)))
 
 
 def test_no_sync_factor_failure_is_reported_as_status():
