@@ -583,9 +583,9 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
                               "x-update", "append", "drop", "#drops", ""};
         for (int k = 0; k < 2; ++k) {
             const double nw = k == 0 ? (double)ceil_div(cn[2] > 0 ? cn[2] : B, 8) : (double)ceil_div(cn[0], 2);
-            fprintf(stderr, "[polish prof] pass %c: %d instances, %.0f waves; per wave (100 MHz ticks):", k ? 'B' : 'A', k ? cn[0] : (cn[2] > 0 ? cn[2] : B), nw);
+            fprintf(stderr, "[polish prof] pass %c: %d instances, %.0f waves; per wave (shader cycles):", k ? 'B' : 'A', k ? cn[0] : (cn[2] > 0 ? cn[2] : B), nw);
             for (int i = 0; i < 15; ++i) fprintf(stderr, " %s %.1f", nm[i], pr[16 * k + i] / nw);
-            fprintf(stderr, " | longest wave %llu ticks", pr[16 * k + 15]);
+            fprintf(stderr, " | longest wave %llu cycles", pr[16 * k + 15]);
             fprintf(stderr, "\n");
         }
     }
