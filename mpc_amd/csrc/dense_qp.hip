@@ -515,8 +515,15 @@ __global__ __launch_bounds__(256) void dense_qp_kernel(DenseParams p) {
 
 }  // namespace
 
+// blocked_setup.hip: the same set-up spread over the GPU (scaling kernels, blocked Cholesky and inverse on the MFMA GEMM)
+bool blocked_setup_fits(int n);
+int blocked_shared_setup(int n, int m, int pe, const double* P, const double* G, const double* A, double* ws, int* iws,
+                         double sigma_rel, hipStream_t st);
+
 static int shared_setup(int n, int m, int p, const double* P, const double* G, const double* A, double* workspace,
                         int* int_workspace, double sigma_rel, hipStream_t stream) {
+    if (blocked_setup_fits(n))
+        return blocked_shared_setup(n, m, p, P, m ? G : nullptr, p ? A : nullptr, workspace, int_workspace, sigma_rel, stream);
     DenseParams d{};
     d.P = P; d.q = workspace; d.G = m ? G : nullptr; d.h = m ? workspace : nullptr; d.A = p ? A : nullptr; d.b = p ? workspace : nullptr;
     long ic = 0;
@@ -580,9 +587,8 @@ int mpcqp_solve_dense_opts(int device_id, int batch, int n, int m, int p, const 
     // workspace of QP 0), then every QP solves on that shared set-up with its own q, h, b
     const bool shared = batch > 1 && sP == 0 && (m == 0 || sG == 0) && (p == 0 || sA == 0);
     if (shared) {
-        d.phase = 1;
-        hipLaunchKernelGGL(dense_qp_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), d);
-        if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+        const int rc = shared_setup(n, m, p, P, G, A, workspace, int_workspace, o.sigma_rel, static_cast<hipStream_t>(stream));
+        if (rc != MPCQP_OK) return rc;
         d.phase = 2;
     } else d.phase = 0;
     hipLaunchKernelGGL(dense_qp_kernel, dim3(batch), dim3(256), 0, static_cast<hipStream_t>(stream), d);

@@ -558,6 +558,12 @@ int gemm_nt_bias(const double* A, long lda, const double* B, long ldb, double* C
     return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, alpha, 0.0, st, bias);
 }
 
+// blocked_setup.hip: C (M, N) = alpha A (M, K) B (N, K)' + beta C
+int gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int M, int N, int K, double alpha,
+            double beta, hipStream_t st) {
+    return launch_gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, alpha, beta, st);
+}
+
 extern "C" {
 
 long mpcqp_rows_workspace(int n, int m, long* per_instance) {

@@ -167,3 +167,60 @@ def test_state_rows_with_one_model_per_instance_match_oracle():
         assert _rel(U[i], s["x"]) <= 1e-6, i
         assert abs(obj[i] - s["primal objective"]) <= 1e-8 * max(abs(s["primal objective"]), 1e-12), i
     assert nopt >= 3
+
+
+@pytest.mark.parametrize("n,m,p", [(96, 40, 0), (131, 57, 3), (257, 300, 0)])
+def test_blocked_shared_setup_matches_numpy(n, m, p):
+    """The multi-workgroup set-up (blocked_setup.hip: scaling kernels, blocked Cholesky and inverse on the MFMA GEMM) leaves
+    in the workspace of QP 0 what the one-workgroup phase of dense_qp_kernel leaves: Ps, (Ps + sigma I)^-1, the scaled
+    rows, the scalings, sigma and the status.  Sizes off the 32-wide panel on purpose."""
+    import ctypes as C
+    import torch
+    from mpc_amd import _lib
+    lib = _lib.load()
+    rng = np.random.default_rng(n)
+    M = rng.standard_normal((n, n + 20))
+    P = M @ M.T / n + np.diag(rng.uniform(0.1, 5.0, n))
+    G = rng.standard_normal((m, n)) * rng.uniform(0.1, 10.0, (m, 1))
+    A = rng.standard_normal((p, n)) if p else None
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.as_tensor(a, dtype=torch.float64, device=dev).contiguous()
+    ni = C.c_long(0)
+    nd = lib.mpcqp_dense_workspace(n, m, p, C.byref(ni))
+    ws = torch.full((nd,), float("nan"), dtype=torch.float64, device=dev)
+    iws = torch.zeros(ni.value, dtype=torch.int32, device=dev)
+    Pt, Gt = t(P), t(G)
+    At = t(A) if p else None
+    ptr = lambda x: C.c_void_p(x.data_ptr()) if x is not None else C.c_void_p(0)
+    rc = lib.mpcqp_dense_shared_setup(0, n, m, p, ptr(Pt), ptr(Gt), ptr(At), ptr(ws), ptr(iws),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    w = ws.cpu().numpy()
+    nn, mc = n * n, m + p
+    V = max(n, mc)
+    Ps = w[:nn].reshape(n, n); Hi = w[nn:2 * nn].reshape(n, n)
+    sigma, status = w[2 * nn], w[2 * nn + 1]
+    Cs = w[4 * nn:4 * nn + mc * n].reshape(mc, n)
+    vec = w[4 * nn + mc * n + 2 * nn:]
+    d, rn = vec[:n], vec[3 * V:3 * V + mc]
+    d_ref = 1.0 / np.sqrt(np.diag(P))
+    assert status == 0.0 and abs(sigma - 1e-6) <= 1e-18
+    assert np.abs(d - d_ref).max() <= 1e-15 * d_ref.max()
+    Ps_ref = P * np.outer(d_ref, d_ref)
+    assert np.abs(Ps - Ps_ref).max() <= 1e-15
+    rows = np.vstack([A, G]) if p else G
+    rn_ref = np.linalg.norm(rows * d_ref, axis=1)
+    assert np.abs(rn - rn_ref).max() <= 1e-13 * rn_ref.max()
+    assert np.abs(Cs - rows * d_ref / rn_ref[:, None]).max() <= 1e-14
+    K = Ps_ref + sigma * np.eye(n)
+    assert np.abs(Hi @ K - np.eye(n)).max() <= 1e-10 * np.linalg.cond(K) ** 0.5
+    assert np.abs(Hi - Hi.T).max() <= 1e-12 * np.abs(Hi).max()
+    # an indefinite Hessian is reported, not factored into NaNs that reach the caller as a solution
+    P2 = P.copy(); k = n // 2 + 3                      # a 2 x 2 principal minor with a negative determinant
+    P2[k, k + 1] = P2[k + 1, k] = 10.0 * np.sqrt(P[k, k] * P[k + 1, k + 1])
+    rc = lib.mpcqp_dense_shared_setup(0, n, m, p, ptr(t(P2)), ptr(Gt), ptr(At), ptr(ws), ptr(iws),
+                                      C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.linalg.eigvalsh(P2).min() < 0 and ws[2 * nn + 1].item() == 3.0
