@@ -27,6 +27,7 @@ struct PolParams {
                                    // kernel, whose factorisation is a Cholesky factor; receiver (that kernel): instances with
                                    // need_big == 3 start from the guess in (z, w) although the solve is cold
     double *hand_buf1, *hand_buf2; int hand_cap2;      // the handle's buffers (first -> second pass, second -> third pass)
+    int q_gate;                    // > 0: run only if the queue holds at least this many; < 0: only if fewer than -q_gate; 0: always
     int cold; int admm_ran; const double* Cq;                      // 1: no (z, w) to start from -- begin with the empty active set
     const int *qin, *qin_count;    // instance queue to take the work from (nullptr: instances 0..B-1)
     int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)

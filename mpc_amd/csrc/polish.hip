@@ -529,7 +529,7 @@ int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
 
 int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
                       const mpcqp_solve_opts& o, hipStream_t st) {
-    PolParams p;
+    PolParams p{};
     p.Hs = h->Hs; p.Hi = h->Hi; p.FsT = h->FsT; p.KuT = h->KuT; p.lbs = h->lbs; p.ubs = h->ubs; p.d = h->d;
     p.x0 = x0; p.z = h->z; p.w = h->w; p.it_ws = h->it_ws; p.rp_ws = h->rp_ws; p.rd_ws = h->rd_ws;
     p.need_big = h->it_ws + h->Bcap;      // int workspace: [iters | need_big | converged]

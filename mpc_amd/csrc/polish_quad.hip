@@ -802,7 +802,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 // COLD: no (z, w) to start from -- the instantiation every default solve uses (it carries neither the iterate registers nor
 // the warm-phase code).
 template <int G, int RP, int KMAX, int THREADS, bool COLD>
-__global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
+__device__ __forceinline__ void oct_body(const PolParams& p) {
     OCT_LAYOUT
     (void)sLb; (void)sUb; (void)sD; (void)sBT; (void)sX0; (void)myR; (void)myV; (void)myA; (void)g; (void)li; (void)CH; (void)XCH; (void)NS; (void)RPL;
     unsigned long long pacc[16] = {};
@@ -812,6 +812,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
     // a plain loop): the loop around this much code costs 30 % in register allocation, more than the staging it saves.
     const int total = p.qin ? *p.qin_count : p.B;
     if ((int)blockIdx.x * IPW >= total) return;
+    if ((p.q_gate > 0 && total < p.q_gate) || (p.q_gate < 0 && total >= -p.q_gate)) return;     // not this instantiation's regime
     // ---- stage the shared data --------------------------------------------------------------
     {   // Hi -> LDS.  The workgroup can do nothing else until this has landed, so the loads are as wide as they can be (16 bytes,
         // contiguous over the workgroup) and all in flight before the first LDS write waits for one
@@ -878,10 +879,15 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 #ifdef POLISH_PROF
     if (lane == 0 && p.prof) {
         unsigned long long tot = 0;
-        for (int i = 0; i < 16; ++i) { atomicAdd(p.prof + (G >= 32 ? 16 : 0) + i, pacc[i]); if (i != 7 && i != 8 && i != 14) tot += pacc[i]; }
-        atomicMax(p.prof + (G >= 32 ? 16 : 0) + 15, tot);       // longest wave: calibrates the tick against the kernel time
+        for (int i = 0; i < 16; ++i) { atomicAdd(p.prof + (G >= 16 ? 16 : 0) + i, pacc[i]); if (i != 7 && i != 8 && i != 14) tot += pacc[i]; }
+        atomicMax(p.prof + (G >= 16 ? 16 : 0) + 15, tot);       // longest wave: calibrates the tick against the kernel time
     }
 #endif
+}
+
+template <int G, int RP, int KMAX, int THREADS, bool COLD>
+__global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
+    oct_body<G, RP, KMAX, THREADS, COLD>(p);
 }
 
 template <int G, int RP, int KMAX, int THREADS, bool COLD>
@@ -1031,9 +1037,9 @@ __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, cons
     }
 }
 
-// The two fast passes: pass A (8 lanes per instance, KMAX = 16) takes the whole batch -- in cold-start order, minus the
-// instances the ordering routes straight to pass B; what outgrows it is queued on the device (q1) and taken by pass B
-// (32 lanes per instance, KMAX = 32); what is left after that is queued in q2 for the wave-per-instance kernel.
+// The two fast passes: pass A (8 lanes per instance, KMAX = 16) takes the whole batch (large cold batches: in cold-start
+// order); what outgrows it is queued on the device (q1) with its working state and taken by pass B (KMAX = 32; 32 or 16
+// lanes per instance by the length of the queue); what outgrows that is queued in q2 for the 64-row pass.
 // Returns 0 on launch, -1 if the shape does not fit this path, a hipError_t (> 0) otherwise.
 int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, int stop_after) {
     if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
@@ -1071,6 +1077,21 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
     b.hand_in = a.hand_out; b.hand_out = p.cold ? p.hand_buf2 : nullptr; b.hand_out_cap = p.hand_cap2; b.hand_zw = 0;
+    // warm solves keep the 32-lane kernel alone: with the iterate registers the 16-lane body spills (166 VGPRs)
+    if (!p.cold) return launch_oct_rp<32, 32, 512>(b, p.B, st);
+    // The length of the queue is only known on the device, so BOTH instantiations are launched and each one gates itself on
+    // it (the other's workgroups leave after one load).  A long queue (the device is full several times over: many binding
+    // rows per instance) is taken 16 lanes per instance, four instances per wave -- throughput; a short one (the headline:
+    // 2-3 % of the batch) 32 lanes per instance -- latency of the slowest instance.  Both share the 32-slot working set and
+    // the state records.  Measured, 65,536 instances, x0 scaled by 1.0 / 1.5 / 2.5: 32 lanes only 0.385 / 0.941 / 3.39 ms,
+    // gated pair 0.383 / 0.877 / 3.16 ms.  (Both bodies inlined into ONE kernel behind a uniform branch were measured too: the
+    // 16-lane body then loses what it gains, 0.941 / 3.37 ms, to the joint register allocation.)
+    constexpr int LONG_QUEUE = 8192;
+    PolParams b16 = b;
+    b16.q_gate = LONG_QUEUE;
+    const int rc16 = launch_oct_rp<16, 32, 512>(b16, p.B, st);
+    if (rc16 != 0) return rc16;
+    b.q_gate = -LONG_QUEUE;
     return launch_oct_rp<32, 32, 512>(b, p.B, st);
 }
 #ifdef OCT_PROBE

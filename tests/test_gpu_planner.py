@@ -272,27 +272,18 @@ def test_predict_matches_prediction_matrices(cfg):
     assert np.abs(X - Xo).max() <= 1e-12 * max(1.0, np.abs(Xo).max())
 
 
-@pytest.mark.parametrize("cfg,batch,x0_scale", [(2, 4096, 1.0), (3, 65536, 1.0), (3, 8192, 2.5)])
-def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale):
-    """BASELINE.json's full sizes (4,096 cart-poles; 65,536 quadrotors): the oracle cannot visit every instance in
-    seconds, so parity at this size is the solver-independent optimality certificate, evaluated for ALL instances
-    (on the device, from H and F themselves): feasibility, stationarity on the free rows, multiplier signs on the
-    active ones, and the reported objective."""
+def _assert_kkt_everywhere(pl, x0, U, u_min, u_max, N):
+    """Solver-independent optimality certificate for ALL instances, evaluated on the device from H and F themselves:
+    feasibility, stationarity on the free rows, multiplier signs on the active ones, the reported objective.
+    Returns the mask of free rows."""
     import torch
-    from mpc_amd.configs import make_config
-    prob = make_config(cfg, batch=batch, seed=1)
-    # scale 2.5: far-out initial states -- large active sets, so the cold-start routing sends many instances straight to
-    # the second pass and some on to the wave-per-instance kernel
-    pl = _planner(prob)
-    x0 = torch.as_tensor(prob["x0"] * x0_scale, device="cuda:0")
-    U = pl.solve(x0).reshape(batch, -1)
+    batch = U.shape[0]
     assert bool((pl.info.status == 0).all())
     H, F, f0 = pl.get("H"), pl.get("F"), pl.get("f0")
     q = x0 @ F.t() + f0
     G = U @ H + q
-    n = H.shape[0]
-    lb = torch.as_tensor(np.tile(prob["u_min"], prob["N"]), device="cuda:0")
-    ub = torch.as_tensor(np.tile(prob["u_max"], prob["N"]), device="cuda:0")
+    lb = torch.as_tensor(np.tile(u_min, N), device="cuda:0")
+    ub = torch.as_tensor(np.tile(u_max, N), device="cuda:0")
     assert bool((U <= ub + 1e-12).all()) and bool((U >= lb - 1e-12).all())
     scale = q.abs().max(dim=1, keepdim=True).values.clamp_min(1.0)
     free = (U < ub - 1e-9) & (U > lb + 1e-9)
@@ -301,11 +292,49 @@ def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale):
     assert bool(((G >= -1e-8 * scale) | (U > lb + 1e-9)).all())
     obj = 0.5 * (U * (U @ H)).sum(1) + (q * U).sum(1)
     assert bool(((pl.info.obj - obj).abs() <= 1e-8 * obj.abs().clamp_min(1e-9)).all())
+    assert free.shape[0] == batch
+    return free
+
+
+@pytest.mark.parametrize("cfg,batch,x0_scale", [(2, 4096, 1.0), (3, 65536, 1.0), (3, 8192, 2.5), (3, 16384, 2.5)])
+def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale):
+    """BASELINE.json's full sizes (4,096 cart-poles; 65,536 quadrotors): the oracle cannot visit every instance in
+    seconds, so parity at this size is the solver-independent optimality certificate, evaluated for ALL instances."""
+    import torch
+    from mpc_amd.configs import make_config
+    prob = make_config(cfg, batch=batch, seed=1)
+    # scale 2.5: far-out initial states -- large active sets, so most instances outgrow the first pass, many the second and
+    # a few the third; at 16,384 instances the second pass's queue is long enough for its 16-lane instantiation
+    pl = _planner(prob)
+    x0 = torch.as_tensor(prob["x0"] * x0_scale, device="cuda:0")
+    U = pl.solve(x0).reshape(batch, -1)
+    free = _assert_kkt_everywhere(pl, x0, U, prob["u_min"], prob["u_max"], prob["N"])
     # the bounds do bind: on average more than once per instance for the quadrotors, now and then for the cart-poles
     assert int((~free).sum()) > (batch if cfg == 3 else 0)
     if x0_scale > 1.0:
         nact = (~free).sum(1)
         assert int((nact > 16).sum()) > batch // 20 and int(nact.max()) > 32     # every pass of the chain is exercised
+        queued = int(pl.get("queues")[0].item())
+        assert (queued >= 8192) == (batch >= 16384)          # which second-pass instantiation ran (polish_quad.hip, LONG_QUEUE)
+
+
+def test_long_queue_second_pass_on_an_odd_shape():
+    """The 16-lane second pass (queues of 8,192 instances or more) on a shape with odd n and n not a multiple of 16: tight
+    input bounds make most instances outgrow the first pass's 16 rows."""
+    import torch
+    from mpc_amd.planner import Planner
+    rng = np.random.default_rng(5)
+    nx, nu, N, batch = 5, 3, 13, 12288          # n = 39
+    A = np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    B = rng.standard_normal((nx, nu)) / np.sqrt(nx)
+    Q = np.eye(nx); R = 0.05 * np.eye(nu)
+    umin, umax = -0.05 * np.ones(nu), 0.04 * np.ones(nu)
+    pl = Planner(nx, nu, N).set_model(A, B).set_cost(Q, R, 2 * Q).set_constraints(umin, umax)
+    x0 = torch.as_tensor(rng.uniform(-3, 3, (batch, nx)), device="cuda:0")
+    U = pl.solve(x0).reshape(batch, -1)
+    free = _assert_kkt_everywhere(pl, x0, U, umin, umax, N)
+    assert int(pl.get("queues")[0].item()) >= 8192
+    assert int((~free).sum(1).max()) > 16
 
 
 @pytest.mark.parametrize("nx,nu,N", [(3, 1, 25), (5, 3, 11), (33, 2, 12), (2, 1, 128)])
