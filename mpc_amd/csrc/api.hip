@@ -121,6 +121,7 @@ int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
     A_(&h->d, nm * n); A_(&h->Hs, nm * n * n); A_(&h->M, n * n); A_(&h->Hi, nm * n * n);
     A_(&h->W1, (w_in_lds ? 1 : nm) * n * n);
     A_(&h->W2, (w_in_lds ? 1 : nm) * n * std::max(n, nx + 1));
+    if (nm == 1) { A_(&h->facL, n * n); A_(&h->facBlk, (size_t)blocked_inverse_scratch((int)n)); }
     A_(&h->Fs1, nm * n * (nx + 1)); A_(&h->Ku1, nm * n * (nx + 1)); A_(&h->Cq, (nx + 1) * (nx + 1));
     A_(&h->FsT, nm * h->NP * (nx + 1)); A_(&h->KuT, nm * h->NP * (nx + 1));
     A_(&h->Mfrag, (size_t)h->NT * h->S * 64); A_(&h->Kbfrag, (size_t)h->NT * h->SX * 64);
@@ -136,7 +137,7 @@ int mpcqp_destroy(mpcqp_handle h) {
     (void)hipSetDevice(h->dev);
     void* ptrs[] = {h->Gam, h->QG, h->Phi, h->H, h->F, h->f0, h->d, h->Hs, h->M, h->Hi, h->W1, h->W2, h->Fs1,
                     h->Ku1, h->Cq, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev, h->mflag,
-                    h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws, h->hbuf1, h->hbuf2};
+                    h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws, h->hbuf1, h->hbuf2, h->facL, h->facBlk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     general_free(h);
     delete h;

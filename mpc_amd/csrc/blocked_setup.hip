@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void scale_rows_kernel(ScaleParams p) {
 // Diagonal block k0 .. k0+kb of W (already carrying the trailing updates): Cholesky factor -> Lout, its inverse ->
 // Dinv (32 x 32, zero padded) and, transposed, into the diagonal block of Tt.  One wave; flag = first failing pivot.
 __global__ __launch_bounds__(64) void diag_block_kernel(const double* W, int n, int k0, int kb, double* Lout, double* Dinv,
-                                                        double* Tt, int* flag) {
+                                                        double* Tt, int* flag, int flag_bits) {
     __shared__ double a[NB][NB + 1];
     __shared__ double t[NB][NB + 1];
     const int lane = threadIdx.x;
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(64) void diag_block_kernel(const double* W, int n, 
     for (int j = 0; j < kb; ++j) {
         double dj = a[j][j];
         if (!(dj > 0.0)) {                      // not positive definite: record it and keep the arithmetic finite
-            if (lane == 0 && *flag < 0) *flag = k0 + j;
+            if (lane == 0) { if (flag_bits) *flag |= 1; else if (*flag < 0) *flag = k0 + j; }
             dj = 1.0;
         }
         const double ljj = sqrt(dj), inv = 1.0 / ljj;
@@ -145,34 +145,23 @@ __global__ void clear_flag_kernel(int* flag) { if (threadIdx.x == 0) *flag = -1;
 
 }  // namespace
 
-// The blocked path needs room for the 32 x 32 inverses and one n x 32 panel inside an n x n scratch block
-bool blocked_setup_fits(int n) { return n >= 2 * NB + NB; }
+// X = W^-1 for a symmetric positive definite W (n x n, destroyed).  Lout, Tt: n x n scratch; blk: blocked_inverse_scratch(n)
+// doubles.  A failing pivot is recorded in *flag (flag_bits: OR 1 into it; else the pivot's index if *flag < 0) and replaced
+// by 1 so that the arithmetic stays finite.  About 5 n / 32 launches on the caller's stream, no synchronisation.
+long blocked_inverse_scratch(int n) { const long nb = (n + NB - 1) / NB; return nb * NB * NB + (long)n * NB; }
 
-// Same contract as phase 1 of dense_qp_kernel: into the workspace of QP 0 go Ps, Hi = (Ps + sigma I)^-1, Cs, d, rn and
-// (sigma, status) in the first two entries of its W block.  Scratch: the W, T, Y and L blocks of QP 0 (n x n each).
-int blocked_shared_setup(int n, int m, int pe, const double* P, const double* G, const double* A, double* ws, int* iws,
-                         double sigma_rel, hipStream_t st) {
-    const long nn = (long)n * n, mc = (long)m + pe, V = std::max<long>(std::max<long>(n, mc), 1);
-    double* Ps = ws; double* Hi = Ps + nn; double* W = Hi + nn; double* Tt = W + nn;
-    double* Cs = Tt + nn; double* Lout = Cs + mc * n; double* Lblk = Lout + nn;
-    double* vec = Lblk + nn;
-    double* d = vec; double* rn = vec + 3 * V; double* sigma = vec + 13 * V;       // sigma parks in QP 0's t1 until the end
+int blocked_spd_inverse(double* W, int n, double* Lout, double* Tt, double* blk, double* X, int* flag, int flag_bits,
+                        hipStream_t st) {
+    const long nn = (long)n * n;
     const int nb = (n + NB - 1) / NB;
-    double* Dinv = Lblk;                                  // nb blocks of 32 x 32
-    double* St = Lblk + (size_t)nb * NB * NB;             // (n, 32) panel
-    int* flag = iws;
-    ScaleParams sp{n, m, pe, P, G, A, d, rn, Ps, W, Cs, sigma, sigma_rel};
-    hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(64), 0, st, flag);
-    hipLaunchKernelGGL(scale_cols_kernel, dim3(1), dim3(256), 0, st, sp);
-    hipLaunchKernelGGL(scale_hessian_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, sp);
-    if (mc > 0) hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, st, sp);
+    double* Dinv = blk;                                   // nb blocks of 32 x 32
+    double* St = blk + (size_t)nb * NB * NB;              // (n, 32) panel
     if (hipMemsetAsync(Tt, 0, nn * sizeof(double), st) != hipSuccess) return MPCQP_EHIP;
-    if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
     int rc = MPCQP_OK;
     for (int b = 0; b < nb && rc == MPCQP_OK; ++b) {
         const int k0 = b * NB, kb = std::min(NB, n - k0), rem = n - k0 - kb;
         double* Db = Dinv + (size_t)b * NB * NB;
-        hipLaunchKernelGGL(diag_block_kernel, dim3(1), dim3(64), 0, st, W, n, k0, kb, Lout, Db, Tt, flag);
+        hipLaunchKernelGGL(diag_block_kernel, dim3(1), dim3(64), 0, st, W, n, k0, kb, Lout, Db, Tt, flag, flag_bits);
         if (rem > 0) {
             double* L21 = Lout + (size_t)(k0 + kb) * n + k0;
             rc = gemm_nt(W + (size_t)(k0 + kb) * n + k0, n, Db, NB, L21, n, rem, kb, kb, 1.0, 0.0, st);       // L21 = W21 D^-T
@@ -187,7 +176,31 @@ int blocked_shared_setup(int n, int m, int pe, const double* P, const double* G,
         rc = gemm_nt(Tt, n, Lout + (size_t)k0 * n, n, St, NB, k0, kb, k0, 1.0, 0.0, st);
         if (rc == MPCQP_OK) rc = gemm_nt(St, NB, Db, NB, Tt + k0, n, k0, kb, kb, -1.0, 0.0, st);
     }
-    if (rc == MPCQP_OK) rc = gemm_nt(Tt, n, Tt, n, Hi, n, n, n, n, 1.0, 0.0, st);       // Hi = T'T
+    if (rc == MPCQP_OK) rc = gemm_nt(Tt, n, Tt, n, X, n, n, n, n, 1.0, 0.0, st);       // X = T'T
+    if (rc == MPCQP_OK && hipGetLastError() != hipSuccess) rc = MPCQP_EHIP;
+    return rc;
+}
+
+// The blocked path needs room for the 32 x 32 inverses and one n x 32 panel inside an n x n scratch block
+bool blocked_setup_fits(int n) { return n >= 2 * NB + NB; }
+
+// Same contract as phase 1 of dense_qp_kernel: into the workspace of QP 0 go Ps, Hi = (Ps + sigma I)^-1, Cs, d, rn and
+// (sigma, status) in the first two entries of its W block.  Scratch: the W, T, Y and L blocks of QP 0 (n x n each).
+int blocked_shared_setup(int n, int m, int pe, const double* P, const double* G, const double* A, double* ws, int* iws,
+                         double sigma_rel, hipStream_t st) {
+    const long nn = (long)n * n, mc = (long)m + pe, V = std::max<long>(std::max<long>(n, mc), 1);
+    double* Ps = ws; double* Hi = Ps + nn; double* W = Hi + nn; double* Tt = W + nn;
+    double* Cs = Tt + nn; double* Lout = Cs + mc * n; double* Lblk = Lout + nn;
+    double* vec = Lblk + nn;
+    double* d = vec; double* rn = vec + 3 * V; double* sigma = vec + 13 * V;       // sigma parks in QP 0's t1 until the end
+    int* flag = iws;
+    ScaleParams sp{n, m, pe, P, G, A, d, rn, Ps, W, Cs, sigma, sigma_rel};
+    hipLaunchKernelGGL(clear_flag_kernel, dim3(1), dim3(64), 0, st, flag);
+    hipLaunchKernelGGL(scale_cols_kernel, dim3(1), dim3(256), 0, st, sp);
+    hipLaunchKernelGGL(scale_hessian_kernel, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, sp);
+    if (mc > 0) hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)((mc + 3) / 4)), dim3(256), 0, st, sp);
+    if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+    const int rc = blocked_spd_inverse(W, n, Lout, Tt, Lblk, Hi, flag, 0, st);
     if (rc != MPCQP_OK) return rc;
     hipLaunchKernelGGL(finish_kernel, dim3(1), dim3(64), 0, st, W, sigma, flag);
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;

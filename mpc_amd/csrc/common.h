@@ -34,6 +34,7 @@ struct mpcqp_handle_s {
     double *H = nullptr, *F = nullptr, *f0 = nullptr;       // (n,n) (n,nx) (n)
     // shared-model solver data (model 0)
     double *d = nullptr, *Hs = nullptr, *M = nullptr, *Hi = nullptr, *W1 = nullptr, *W2 = nullptr;
+    double *facL = nullptr, *facBlk = nullptr;     // shared model: scratch of the blocked inverses (blocked_setup.hip)
     double *Fs1 = nullptr;      // (n, nx+1): [Fs | f0s]   qs = Fs1 [x0;1]
     double *Cq = nullptr;       // (nx+1, nx+1): Fs1' Ku1 (shared model): qs'x_unc = [x0;1]' Cq [x0;1]
     double *Ku1 = nullptr;      // (n, nx+1): [Ku | ku]    x_unc = Ku1 [x0;1]
@@ -89,6 +90,10 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
                       const mpcqp_solve_opts& o, hipStream_t st);
 int launch_shift(mpcqp_handle h, hipStream_t st);
 bool admm_shared_box_supported(int NT, int S);
+// blocked_setup.hip: X = W^-1 (W symmetric positive definite, destroyed) spread over the GPU; scratch sizes in doubles
+long blocked_inverse_scratch(int n);
+int blocked_spd_inverse(double* W, int n, double* Lout, double* Tt, double* blk, double* X, int* flag, int flag_bits,
+                        hipStream_t st);
 int factor_general(mpcqp_handle h, hipStream_t st);
 int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st);
 void general_free(mpcqp_handle h);

@@ -65,95 +65,108 @@ __device__ void inverse_from_chol(const double* W, double* T, double* X, int n) 
     __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void factor_kernel(FacParams f) {
-    __shared__ double red[256];
-    const int n = f.n, nx = f.nx, nx1 = f.nx + 1, tid = threadIdx.x;
-    if (tid == 0) f.flag[0] = 0;
-    __syncthreads();
-    for (int i = tid; i < n; i += 256) {
-        const double hii = f.H[(size_t)i * n + i];
-        if (!(hii > 0.0)) { f.flag[0] |= 1; f.d[i] = 1.0; }
-        else f.d[i] = 1.0 / sqrt(hii);
-    }
-    __syncthreads();
-    for (int idx = tid; idx < n * n; idx += 256) {
-        const int i = idx / n, j = idx % n;
-        // symmetrise so that rounding in the assembly cannot leave Hs unsymmetric
-        const double v = 0.5 * (f.H[idx] + f.H[(size_t)j * n + i]) * f.d[i] * f.d[j];
-        f.Hs[idx] = v;
-        f.W1[idx] = v;
-    }
-    __syncthreads();
-    chol_inplace(f.W1, n, f.flag);
-    inverse_from_chol(f.W1, f.W2, f.Hi, n);
+// ---- shared model: the set-up as a chain of small grids (it was ONE 256-thread workgroup working in global memory behind
+// ~1,000 barriers: 4.0 ms at n = 120).  The two inverses run blocked on the MFMA GEMM
+// (blocked_setup.hip); everything else is element-wise or a dot product per output element.
 
-    // spectrum bounds: lmax <= ||Hs||_inf, lmin >= 1/||Hi||_inf
+// d, Hs = d H d (symmetrised so that rounding in the assembly cannot leave it unsymmetric), W1 = Hs
+__global__ __launch_bounds__(256) void fac_scale_kernel(FacParams f) {
+    const int n = f.n;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    const int i = idx / n, j = idx - i * n;
+    const double hii = f.H[(size_t)i * n + i], hjj = f.H[(size_t)j * n + j];
+    const double di = hii > 0.0 ? 1.0 / sqrt(hii) : 1.0, dj = hjj > 0.0 ? 1.0 / sqrt(hjj) : 1.0;
+    if (i == j) { f.d[i] = di; if (!(hii > 0.0)) atomicOr(f.flag, 1); }
+    const double v = 0.5 * (f.H[idx] + f.H[(size_t)j * n + i]) * di * dj;
+    f.Hs[idx] = v;
+    f.W1[idx] = v;
+}
+
+// spectrum bounds lmax <= |Hs|_inf, lmin >= 1 / |Hi|_inf  ->  rho;  rho_dev = (rho, lmax, lmin, 0)
+__global__ __launch_bounds__(256) void fac_rho_kernel(FacParams f) {
+    __shared__ double ra[4], rb[4];
+    const int n = f.n, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double a = 0.0, b = 0.0;
-    for (int i = tid; i < n; i += 256) {
+    for (int i = wave; i < n; i += 4) {         // a wave per row, lanes along the columns
         double sa = 0.0, sb = 0.0;
-        for (int j = 0; j < n; ++j) { sa += fabs(f.Hs[(size_t)i * n + j]); sb += fabs(f.Hi[(size_t)i * n + j]); }
+        for (int j = lane; j < n; j += 64) { sa += fabs(f.Hs[(size_t)i * n + j]); sb += fabs(f.Hi[(size_t)i * n + j]); }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { sa += __shfl_xor(sa, o); sb += __shfl_xor(sb, o); }
         a = fmax(a, sa); b = fmax(b, sb);
     }
-    red[tid] = a; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
-    const double lmax = red[0]; __syncthreads();
-    red[tid] = b; __syncthreads();
-    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
-    const double lmin = 1.0 / red[0]; __syncthreads();
-    const double rho = f.rho_in > 0.0 ? f.rho_in : 0.1 * sqrt(lmax * lmin);
-    if (tid == 0) { f.rho_dev[0] = rho; f.rho_dev[1] = lmax; f.rho_dev[2] = lmin; }
-
-    for (int idx = tid; idx < n * n; idx += 256) f.W1[idx] = f.Hs[idx] + ((idx / n == idx % n) ? rho : 0.0);
+    if (lane == 0) { ra[wave] = a; rb[wave] = b; }
     __syncthreads();
-    chol_inplace(f.W1, n, f.flag);
-    inverse_from_chol(f.W1, f.W2, f.M, n);
+    if (threadIdx.x == 0) {
+        const double lmax = fmax(fmax(ra[0], ra[1]), fmax(ra[2], ra[3]));
+        const double lmin = 1.0 / fmax(fmax(rb[0], rb[1]), fmax(rb[2], rb[3]));
+        f.rho_dev[0] = f.rho_in > 0.0 ? f.rho_in : 0.1 * sqrt(lmax * lmin);
+        f.rho_dev[1] = lmax; f.rho_dev[2] = lmin; f.rho_dev[3] = 0.0;
+    }
+}
 
-    // affine maps from [x0; 1]
-    for (int idx = tid; idx < n * nx1; idx += 256) {
-        const int i = idx / nx1, c = idx % nx1;
-        f.Fs1[idx] = f.d[i] * (c < nx ? f.F[(size_t)i * nx + c] : f.f0[i]);
+__global__ __launch_bounds__(256) void fac_shift_kernel(FacParams f) {
+    const int n = f.n;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * n) return;
+    f.W1[idx] = f.Hs[idx] + ((idx / n == idx % n) ? f.rho_dev[0] : 0.0);
+}
+
+// affine maps from [x0; 1]: Fs1 = [d F | d f0], Ku1 = -Hi Fs1, Kb1 = -M Fs1 (into W2); one thread per element
+__global__ __launch_bounds__(256) void fac_maps_kernel(FacParams f) {
+    const int n = f.n, nx = f.nx, nx1 = nx + 1;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= n * nx1) return;
+    const int i = idx / nx1, c = idx - i * nx1;
+    double su = 0.0, sb = 0.0;
+    for (int k = 0; k < n; ++k) {
+        const double fv = f.d[k] * (c < nx ? f.F[(size_t)k * nx + c] : f.f0[k]);
+        su -= f.Hi[(size_t)i * n + k] * fv;
+        sb -= f.M[(size_t)i * n + k] * fv;
     }
-    __syncthreads();
-    double* Kb1 = f.W2;     // reuse scratch: (n, nx+1)
-    for (int idx = tid; idx < n * nx1; idx += 256) {
-        const int i = idx / nx1, c = idx % nx1;
-        double su = 0.0, sb = 0.0;
-        for (int k = 0; k < n; ++k) {
-            const double fv = f.Fs1[(size_t)k * nx1 + c];
-            su -= f.Hi[(size_t)i * n + k] * fv;
-            sb -= f.M[(size_t)i * n + k] * fv;
-        }
-        f.Ku1[idx] = su;
-        Kb1[idx] = sb;
+    f.Fs1[idx] = f.d[i] * (c < nx ? f.F[(size_t)i * nx + c] : f.f0[i]);
+    f.Ku1[idx] = su;
+    f.W2[idx] = sb;
+}
+
+// how far the explicit inverse is from exact: max |Hs Hi - I| -> rho_dev[3] (the active-set stage refines if this is large)
+__global__ __launch_bounds__(256) void fac_resid_kernel(FacParams f) {
+    __shared__ double red[256];
+    const int n = f.n, tid = threadIdx.x;
+    const int idx = blockIdx.x * 256 + tid;
+    double e = 0.0;
+    if (idx < n * n) {
+        const int i = idx / n, j = idx - i * n;
+        double sacc = (i == j) ? -1.0 : 0.0;
+        for (int k = 0; k < n; ++k) sacc += f.Hs[(size_t)i * n + k] * f.Hi[(size_t)k * n + j];
+        e = fabs(sacc);
+        if (!(e == e)) e = 1e300;       // NaN (a failed factorisation): report it as a large residual
     }
-    // how far the explicit inverse is from exact: max |Hs Hi - I| (the polish refines if this is large)
-    {
-        double e = 0.0;
-        for (int idx = tid; idx < n * n; idx += 256) {
-            const int i = idx / n, j = idx % n;
-            double sacc = (i == j) ? -1.0 : 0.0;
-            for (int k = 0; k < n; ++k) sacc += f.Hs[(size_t)i * n + k] * f.Hi[(size_t)k * n + j];
-            e = fmax(e, fabs(sacc));
-        }
-        red[tid] = e; __syncthreads();
-        for (int sft = 128; sft > 0; sft >>= 1) { if (tid < sft) red[tid] = fmax(red[tid], red[tid + sft]); __syncthreads(); }
-        if (tid == 0) f.rho_dev[3] = red[0];
-        __syncthreads();
-    }
-    // Cq = Fs1' Ku1: the active-set kernels get qs'x_unc as a quadratic form in [x0; 1] instead of forming qs
-    for (int idx = tid; idx < nx1 * nx1; idx += 256) {
+    red[tid] = e; __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if (tid < s) red[tid] = fmax(red[tid], red[tid + s]); __syncthreads(); }
+    // non-negative doubles order like their bit patterns
+    if (tid == 0) atomicMax(reinterpret_cast<unsigned long long*>(f.rho_dev + 3), (unsigned long long)__double_as_longlong(red[0]));
+}
+
+// Cq = Fs1' Ku1 (the active-set kernels get qs'x_unc as a quadratic form in [x0; 1]), the transposed maps, the scaled
+// bounds and the MFMA A-operand fragment images: frag (t, s), lane l  <-  X[16t + (l&15)][4s + (l>>4)]
+__global__ __launch_bounds__(256) void fac_tail_kernel(FacParams f) {
+    const int n = f.n, nx1 = f.nx + 1, NP = 16 * f.NT;
+    const int gid = blockIdx.x * 256 + threadIdx.x, gsz = gridDim.x * 256;
+    const double rho = f.rho_dev[0];
+    const double* Kb1 = f.W2;
+    for (int idx = gid; idx < nx1 * nx1; idx += gsz) {
         const int a = idx / nx1, b = idx % nx1;
         double sacc = 0.0;
         for (int i = 0; i < n; ++i) sacc += f.Fs1[(size_t)i * nx1 + a] * f.Ku1[(size_t)i * nx1 + b];
         f.Cq[idx] = sacc;
     }
-    const int NP = 16 * f.NT;
-    for (int idx = tid; idx < NP * nx1; idx += 256) {
+    for (int idx = gid; idx < NP * nx1; idx += gsz) {
         const int c = idx / NP, i = idx % NP;
         f.FsT[idx] = i < n ? f.Fs1[(size_t)i * nx1 + c] : 0.0;
         f.KuT[idx] = i < n ? f.Ku1[(size_t)i * nx1 + c] : 0.0;
     }
-    for (int i = tid; i < NP; i += 256) {
+    for (int i = gid; i < NP; i += gsz) {
         double lo = 0.0, hi = 0.0;
         if (i < n) {
             const int j = f.per_stage ? i : (i % f.nu);
@@ -162,14 +175,12 @@ __global__ __launch_bounds__(256) void factor_kernel(FacParams f) {
         }
         f.lbs[i] = lo; f.ubs[i] = hi;
     }
-    __syncthreads();
-    // A-operand fragment images: frag (t, s), lane l  <-  X[16t + (l&15)][4s + (l>>4)]
-    for (int idx = tid; idx < f.NT * f.S * 64; idx += 256) {
+    for (int idx = gid; idx < f.NT * f.S * 64; idx += gsz) {
         const int l = idx & 63, ts = idx >> 6, t = ts / f.S, s = ts % f.S;
         const int i = 16 * t + (l & 15), k = 4 * s + (l >> 4);
         f.Mfrag[idx] = (i < n && k < n) ? rho * f.M[(size_t)i * n + k] : 0.0;
     }
-    for (int idx = tid; idx < f.NT * f.SX * 64; idx += 256) {
+    for (int idx = gid; idx < f.NT * f.SX * 64; idx += gsz) {
         const int l = idx & 63, ts = idx >> 6, t = ts / f.SX, s = ts % f.SX;
         const int i = 16 * t + (l & 15), k = 4 * s + (l >> 4);
         const bool in = (i < n && k < nx1);
@@ -588,9 +599,24 @@ int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
     f.lbs = h->lbs; f.ubs = h->ubs; f.rho_dev = h->rho_dev; f.flag = h->flag_dev;
     f.n = h->n; f.nx = h->dims.nx; f.nu = h->dims.nu; f.NT = h->NT; f.S = h->S; f.SX = h->SX;
     f.per_stage = h->per_stage; f.rho_in = rho;
-    hipLaunchKernelGGL(factor_kernel, dim3(1), dim3(256), 0, st, f);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { h->err = std::string("factor launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
+    const int n = h->n, nn = n * n, nx1 = h->dims.nx + 1;
+    auto fail = [&](const char* what, hipError_t e) {
+        h->err = std::string("factor: ") + what + ": " + hipGetErrorString(e); return MPCQP_EHIP;
+    };
+    hipError_t e = hipMemsetAsync(h->flag_dev, 0, sizeof(int), st);
+    if (e != hipSuccess) return fail("memset", e);
+    hipLaunchKernelGGL(fac_scale_kernel, dim3(ceil_div(nn, 256)), dim3(256), 0, st, f);
+    int rc = blocked_spd_inverse(h->W1, n, h->facL, h->W2, h->facBlk, h->Hi, h->flag_dev, 1, st);       // Hi = Hs^-1
+    if (rc != MPCQP_OK) { h->err = "factor: blocked inverse of Hs failed to launch"; return rc; }
+    hipLaunchKernelGGL(fac_rho_kernel, dim3(1), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(fac_shift_kernel, dim3(ceil_div(nn, 256)), dim3(256), 0, st, f);
+    rc = blocked_spd_inverse(h->W1, n, h->facL, h->W2, h->facBlk, h->M, h->flag_dev, 1, st);            // M = (Hs + rho I)^-1
+    if (rc != MPCQP_OK) { h->err = "factor: blocked inverse of Hs + rho I failed to launch"; return rc; }
+    hipLaunchKernelGGL(fac_maps_kernel, dim3(ceil_div(n * nx1, 256)), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(fac_resid_kernel, dim3(ceil_div(nn, 256)), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(fac_tail_kernel, dim3(std::max(1, std::min(64, ceil_div(h->NT * h->S * 64, 256)))), dim3(256), 0, st, f);
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail("launch", e);
     return MPCQP_OK;
 }
 
