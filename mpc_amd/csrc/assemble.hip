@@ -7,7 +7,9 @@
 //   H, gradient    HelperFuncs.py:6-11 getQuadProgCostFunction (Q = J'WJ, f = -J'Wc) with
 //                  J = [Gamma; I], W = blkdiag(Qbar, Rbar); LaunchPlannerQPFormulation.py:151-162
 //
-// One 256-thread workgroup per model.  Phase 1 walks the horizon: row block k of Gamma is
+// One 256-thread workgroup per model when there are many models; ONE shared model is spread over the GPU instead: the
+// rollout's chain is independent per column of Gamma, so gridDim.y workgroups walk the horizon on their own column tiles,
+// and a second launch spreads the tiles of H and F (it starts when all of Gamma is there).  Phase 1 walks the horizon: row block k of Gamma is
 // A_k times row block k-1 with B_k dropped on the block diagonal (the state-space form of the
 // reference's prefix sums); Qbar Gamma is formed on the fly.  Phase 2 is the SYRK-shaped
 // contraction Gamma'(Qbar Gamma) on v_mfma_f64_16x16x4_f64, lower tiles only and mirrored, with
@@ -23,6 +25,7 @@ struct AsmParams {
     long xref_stride, uref_stride;       // doubles between the references of consecutive models (0: shared)
     double *Gam, *QG, *Phi, *H, *F, *f0;
     int nx, nu, N, n, p, tv;
+    int phases;     // bit 0: the rollout; bit 1: H, F, f0.  One model: two launches, each spread over gridDim.y workgroups
 };
 
 // barrier that orders LDS traffic only: the rollout's global stores (Gamma, Qbar Gamma, Phi rows) stay in flight across
@@ -51,15 +54,14 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     double* sA = sQ + 2 * nx * nx;                      // the model's A_k, B_k (a.ab_in_lds): the rollout is a chain of
     double* sB = sA + (a.tv ? N : 1) * nx * nx;         // N dependent steps, so nothing in it should wait on global memory
     const int tid = threadIdx.x;
+    const int Y = gridDim.y, y = blockIdx.y;
+    if (a.phases & 1) {
     for (int i = tid; i < nx * nx; i += 256) { sQ[i] = a.Q[i]; sQ[nx * nx + i] = a.P[i]; }
     if (a.ab_in_lds) {
         for (int i = tid; i < (int)strideA; i += 256) sA[i] = Am[i];
         for (int i = tid; i < (int)strideB; i += 256) sB[i] = Bm[i];
     }
 
-#ifdef ASM_PROF
-    long long c0 = wall_clock64();
-#endif
     // ---- phase 1: rollout --------------------------------------------------------------
     if (a.rows_in_lds) for (int i = tid; i < nx * n; i += 256) rowG[i] = 0.0;
     for (int i = tid; i < nx * nx; i += 256) rowP[i] = (i / nx == i % nx) ? 1.0 : 0.0;
@@ -69,6 +71,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     // bounds this kernel when there is one small model per instance
     const int lane_ = tid & 63, wave_ = tid >> 6, col_ = lane_ & 15, kq_ = lane_ >> 4;
     const int RTn = (nx + 15) / 16, CTn = (n + 15) / 16, KS = (nx + 3) / 4;
+    // this workgroup's column tiles of Gamma: y, y + Y, ...; the Phi chain belongs to workgroup 0
+    const int nct = y < CTn ? (CTn - y + Y - 1) / Y : 0;
+    const int ntG = RTn * nct, ntP = y == 0 ? RTn * RTn : 0;
     for (int k = 0; k < N; ++k) {
         const double* Ak = (a.ab_in_lds ? sA : Am) + (a.tv ? (size_t)k * nx * nx : 0);
         const double* Bk = (a.ab_in_lds ? sB : Bm) + (a.tv ? (size_t)k * nx * nu : 0);
@@ -79,11 +84,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
         double* pout = rowP + ((k + 1) & 1) * nx * nx;
         const int cB = k * nu;                          // first column of stage k
         // tiles 0 .. RTn*CTn-1: Gamma row block;  the next RTn*RTn: Phi row block
-        for (int t = wave_; t < RTn * CTn + RTn * RTn; t += 4) {
-            const bool isP = t >= RTn * CTn;
-            const int tt = isP ? t - RTn * CTn : t;
-            const int wdt = isP ? nx : n, CT = isP ? RTn : CTn;
-            const int rt = tt / CT, ct = tt % CT;
+        for (int t = wave_; t < ntG + ntP; t += 4) {
+            const bool isP = t >= ntG;
+            const int tt = isP ? t - ntG : t;
+            const int wdt = isP ? nx : n;
+            const int rt = isP ? tt / RTn : tt / nct, ct = isP ? tt % RTn : y + Y * (tt % nct);
             const double* src = isP ? pin : gin;
             const int ra = 16 * rt + col_, cb = 16 * ct + col_;
             d4 acc = {0, 0, 0, 0};
@@ -111,8 +116,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
             }
         }
         if (a.rows_in_lds) lds_barrier(); else { __threadfence_block(); __syncthreads(); }
-        for (int t = wave_; t < RTn * CTn; t += 4) {            // Qbar Gamma row block
-            const int rt = t / CTn, ct = t % CTn;
+        for (int t = wave_; t < ntG; t += 4) {                  // Qbar Gamma row block
+            const int rt = t / nct, ct = y + Y * (t % nct);
             const int ra = 16 * rt + col_, cb = 16 * ct + col_;
             d4 acc = {0, 0, 0, 0};
             for (int s = 0; s < KS; ++s) {
@@ -129,12 +134,11 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
         }
         if (a.rows_in_lds) lds_barrier(); else { __threadfence_block(); __syncthreads(); }
     }
+    }
+    if (!(a.phases & 2)) return;
     __threadfence_block();
     __syncthreads();
 
-#ifdef ASM_PROF
-    long long c1 = wall_clock64();
-#endif
     // ---- phase 2: H = Gam' QG + Rbar on fp64 MFMA, lower tiles, mirrored ----------------------
     const int lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     int tile = 0;
     for (int ti = 0; ti < NT; ++ti)
         for (int tj = 0; tj <= ti; ++tj, ++tile) {
-            if ((tile & 3) != wave) continue;
+            if (tile % (4 * Y) != wave + 4 * y) continue;
             // rows of Gamma above stage(first column of the later tile) * nx are zero in that tile
             const int first_stage = (16 * ti) / nu;
             const int s0 = (first_stage * nx) / 4;
@@ -170,14 +174,10 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
             }
         }
 
-#ifdef ASM_PROF
-    __syncthreads();
-    long long c2 = wall_clock64();
-#endif
     // ---- phase 3: F = QG' Phi (n, nx) and f0 = -QG' xr - Rbar ur --------------------------------
     {
         const int NXT = (nx + 15) / 16;
-        for (int t = wave; t < NT * NXT; t += 4) {
+        for (int t = wave + 4 * y; t < NT * NXT; t += 4 * Y) {
             const int ti = t / NXT, tj = t % NXT;
             d4 acc = {0, 0, 0, 0};
             const int ci = 16 * ti + col, cj = 16 * tj + col;
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
         __syncthreads();
         double* part = reinterpret_cast<double*>(smem);         // 4 x 64
         const int pq = (p + 3) / 4, r0 = wave * pq, r1 = min(p, r0 + pq);
-        for (int i0 = 0; i0 < n; i0 += 64) {
+        for (int i0 = 64 * y; i0 < n; i0 += 64 * Y) {
             const int i = i0 + lane;
             double s = 0.0;
             if (i < n && a.xref) {
@@ -221,10 +221,6 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
             __syncthreads();
         }
     }
-#ifdef ASM_PROF
-    __syncthreads();
-    if (tid == 0 && (m % 2048) == 0) printf("model %d: rollout %lld H %lld F/f0 %lld (x10 ns)\n", m, c1 - c0, c2 - c1, wall_clock64() - c2);
-#endif
 }
 
 }  // namespace
@@ -247,7 +243,18 @@ int launch_assemble(mpcqp_handle h, hipStream_t st) {
     if (lds > 160 * 1024) { h->err = "assemble: nx too large for the LDS buffers"; return MPCQP_ENOTIMPL; }
     hipError_t e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&assemble_kernel), lds);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return MPCQP_EHIP; }
-    hipLaunchKernelGGL(assemble_kernel, dim3(h->dims.n_models), dim3(256), lds, st, a);
+    if (h->dims.n_models > 1) {
+        a.phases = 3;
+        hipLaunchKernelGGL(assemble_kernel, dim3(h->dims.n_models), dim3(256), lds, st, a);
+    } else {
+        // one shared model: the rollout over up to 32 workgroups (one or more column tiles each), then the tiles of H and F
+        // over enough workgroups that a wave has a handful of them
+        const int CTn = ceil_div(a.n, 16), tiles = CTn * (CTn + 1) / 2;
+        a.phases = 1;
+        hipLaunchKernelGGL(assemble_kernel, dim3(1, std::min(CTn, 32)), dim3(256), lds, st, a);
+        a.phases = 2;
+        hipLaunchKernelGGL(assemble_kernel, dim3(1, std::max(1, std::min(256, ceil_div(tiles, 8)))), dim3(256), lds, st, a);
+    }
     e = hipGetLastError();
     if (e != hipSuccess) { h->err = std::string("assemble launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
     return MPCQP_OK;
