@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch at 65,536 instances from the committed PMC passes (2 * FETCH_SIZE + WRITE_SIZE, KB -> bytes)
 PMC = {
     "admm": ((2 * 49314.40 + 213303.90) * 1024.0, "profiles/r01_v5_pmc.csv (admm_shared_box_kernel)"),
-    "pass_a": ((2 * 7099.49 + 195100.30) * 1024.0, "profiles/r02_pmc.csv (polish_oct_kernel<8, 8, 16, 512, true>, the first pass)"),
+    "pass_a": ((2 * 7135.20 + 195092.22) * 1024.0, "profiles/r02_pmc.csv (polish_oct_kernel<8, 8, 16, 512, true>, the first pass)"),
 }
 
 
@@ -297,7 +297,10 @@ class BoxWorkload:
         both_ms = timed(lambda: pl.solve(x0, **opts), reps)
         # the first (and longest) active-set launch alone: stages bit 2 stops after it, bit 3 after the cold-start
         # ordering kernels that run before it (diagnostic modes: queued instances stay open)
-        order_ms = max(timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms, 0.0)
+        # (the ordering kernels only run for cold batches of 24,576 instances or more, polish_quad.hip; below that "stages=15"
+        # times an empty solve, i.e. the host's launch cost, which is not something to subtract from a kernel time)
+        ordered = B >= 24576 and not admm_on
+        order_ms = max(timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms, 0.0) if ordered else 0.0
         pass_a_ms = max(timed(lambda: pl.solve(x0, stages=7, **opts), reps) - admm_ms - order_ms, 0.0)
         nlat = max(20, min(args.steps, 100))
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nlat)]
@@ -345,7 +348,9 @@ class BoxWorkload:
                         "traffic_source": PMC["pass_a"][1] + ", scaled with the batch" if args.config == 3 else None,
                         "algorithmic_bytes": pa_bytes, "launch_ms": pass_a_ms,
                         "note": "latency / VALU-issue bound by construction: ~8 dependent active-set steps per instance in "
-                                "fp64; VALU busy fraction and instruction counts in DESIGN.md section 4"}
+                                "fp64; VALU busy fraction and instruction counts in DESIGN.md section 4a" +
+                                ("" if B >= 16384 else "; at this batch size the launch is shorter than the host's cost of "
+                                 "issuing it (~20 us per launch pair): launch_ms is host-bound")}
         config = {"workload": f"{self.name}, {self.global_batch} random x0 "
                               f"{'split over' if args.scaling == 'strong' else 'per GPU on'} {ranks.world} GPU(s), "
                               "shared LTI model",
