@@ -490,39 +490,75 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     }
     __syncthreads();
     TICK(t_x)
-    if (status == 0)
-        for (int itr = 0; itr < p.refine; ++itr) {
-            blk_symv(t1, s.Ps, x, n, vs, part);             // g = Ps x + qs + N' lam
-            TICK(t_sv)
-            for (int j = tid; j < n; j += RT) {
-                double v = t1[j] + qs[j];
-                for (int a = 0; a < k; ++a) v += s.Cs[(size_t)act[a] * n + j] * lam[a];
-                t1[j] = v;
-            }
-            __syncthreads();
-            TICK(t_nl)
-            blk_symv(dv, s.Hi, t1, n, vs, part);            // dv = Hi g
-            TICK(t_sv)
-            for (int a = wave; a < k; a += RT / 64) {       // N (x - dv) - cs on the active rows
-                const double* na = s.Cs + (size_t)act[a] * n;
-                double v = 0.0;
-                for (int j = lane; j < n; j += 64) v += na[j] * (x[j] - dv[j]);
-                v = wave_sum(v);
-                if (lane == 0) dl[a] = v - cs[act[a]];
-            }
-            __syncthreads();
-            if (wave == 0) { w0_fwd(L, k, dl, lane); w0_bwd(L, k, dl, lane); }
-            __syncthreads();
-            for (int j = tid; j < n; j += RT) {
-                double v = -dv[j];
-                for (int a = 0; a < k; ++a) v -= p.CH[(size_t)act[a] * n + j] * dl[a];
-                x[j] += v;
-            }
-            __syncthreads();
-            if (wave == 0) { for (int a = lane; a < k; a += 64) lam[a] += dl[a]; }
-            __syncthreads();
-            TICK(t_rows)
+    // Is (x, lam) already optimal to rounding level?  x = xu - Hi N_A' lam holds by construction, so the stationarity
+    // residual is g = (I - Ps Hi)(qs + N' lam): bounded by eps |qs + N' lam|_inf with eps = |I - Ps Hi|_inf from the set-up,
+    // and the rows of the active set can be checked directly -- no matvec with a shared n x n matrix, which is what this
+    // tail used to spend its time on (every workgroup of the batch streaming the same 2.9 MB matrices through L2, three
+    // times).  Only if the bound does not certify it is g itself formed (one matvec), and only if g is not small either does
+    // a refinement round run (two more).
+    const double eps = s.W0[2], tol = 1e-11;
+    int rounds = 0;
+    bool have_t1 = false;
+    for (;;) {
+        double wm = 0.0, qm = 0.0;
+        for (int j = tid; j < n; j += RT) {                 // w = qs + N' lam
+            double v = qs[j];
+            for (int a = 0; a < k; ++a) v += s.Cs[(size_t)act[a] * n + j] * lam[a];
+            dv[j] = v;
+            wm = fmax(wm, fabs(v)); qm = fmax(qm, fabs(qs[j]));
         }
+        double rm = 0.0, cm = 0.0;
+        for (int a = wave; a < k; a += RT / 64) {           // N x - cs on the active rows; lam_a (N xu - cs)_a for the objective
+            const double* na = s.Cs + (size_t)act[a] * n;
+            double v = 0.0, v0 = 0.0;
+            for (int j = lane; j < n; j += 64) { v += na[j] * x[j]; v0 += na[j] * xu[j]; }
+            v = wave_sum(v) - cs[act[a]]; v0 = wave_sum(v0) - cs[act[a]];
+            rm = fmax(rm, fabs(v)); cm = fmax(cm, fabs(cs[act[a]]));
+            if (lane == 0) { dl[a] = v; rv[a] = lam[a] * v0; }
+        }
+        // block maxima through the arg-max reduction (values only)
+        double o; int oi;
+        blk_argmax(wm, 0, red, redi, o, oi); wm = o;
+        blk_argmax(qm, 0, red, redi, o, oi); qm = o;
+        blk_argmax(rm, 0, red, redi, o, oi); rm = o;
+        blk_argmax(cm, 0, red, redi, o, oi); cm = o;
+        __syncthreads();
+        TICK(t_nl)
+        if (status != 0 || p.refine == 0) break;
+        const bool rows_ok = rm <= tol * fmax(1.0, cm);
+        if (rows_ok && eps * wm <= tol * fmax(1.0, qm)) break;                   // certified by the bound
+        blk_symv(t1, s.Ps, x, n, vs, part);
+        have_t1 = true;
+        TICK(t_sv)
+        double gm = 0.0;
+        for (int j = tid; j < n; j += RT) { const double v = t1[j] + dv[j]; dv[j] = v; gm = fmax(gm, fabs(v)); }     // g itself
+        blk_argmax(gm, 0, red, redi, o, oi); gm = o;
+        __syncthreads();
+        if ((rows_ok && gm <= tol * fmax(1.0, qm)) || rounds >= p.refine) break;
+        ++rounds;
+        have_t1 = false;
+        blk_symv(dv, s.Hi, dv, n, vs, part);                // dv = Hi g  (the operand is staged in LDS before dv is written)
+        TICK(t_sv)
+        for (int a = wave; a < k; a += RT / 64) {           // N (x - dv) - cs = (N x - cs) - N dv on the active rows
+            const double* na = s.Cs + (size_t)act[a] * n;
+            double v = 0.0;
+            for (int j = lane; j < n; j += 64) v += na[j] * dv[j];
+            v = wave_sum(v);
+            if (lane == 0) dl[a] -= v;
+        }
+        __syncthreads();
+        if (wave == 0) { w0_fwd(L, k, dl, lane); w0_bwd(L, k, dl, lane); }
+        __syncthreads();
+        for (int j = tid; j < n; j += RT) {
+            double v = -dv[j];
+            for (int a = 0; a < k; ++a) v -= p.CH[(size_t)act[a] * n + j] * dl[a];
+            x[j] += v;
+        }
+        __syncthreads();
+        if (wave == 0) { for (int a = lane; a < k; a += 64) lam[a] += dl[a]; }
+        __syncthreads();
+        TICK(t_rows)
+    }
 
     // ---- outputs ----------------------------------------------------------------------------------------------------------
     double* xo = p.x + (size_t)qi * n;
@@ -532,10 +568,15 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     if (p.z) for (int a = tid; a < k; a += RT) p.z[(size_t)qi * m + act[a]] = lam[a] / s.rn[act[a]];
     __syncthreads();
     TICK(t_out)
-    blk_symv(t1, s.Ps, x, n, vs, part);
-    TICK(t_sv)
+    // objective: at an untouched active-set solution f(x) = f(xu) + 1/2 lam' S lam = 1/2 qs' xu + 1/2 sum_a lam_a (N xu - cs)_a;
+    // after a refinement round, or for an instance that did not finish, from x itself
+    if (!have_t1 && (status != 0 || rounds > 0)) { blk_symv(t1, s.Ps, x, n, vs, part); have_t1 = true; }
     double po = 0.0;
-    for (int j = tid; j < n; j += RT) po += x[j] * (0.5 * t1[j] + qs[j]);
+    if (have_t1) { for (int j = tid; j < n; j += RT) po += x[j] * (0.5 * t1[j] + qs[j]); }
+    else {
+        for (int j = tid; j < n; j += RT) po += 0.5 * qs[j] * xu[j];
+        for (int a = tid; a < k; a += RT) po += 0.5 * rv[a];
+    }
     const double obj = blk_sum(po, red);
 #ifdef ROWS_PROF
     if (tid == 0 && (qi & 63) == 0)
@@ -548,6 +589,17 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         if (p.status) p.status[qi] = status;
         if (p.iters) p.iters[qi] = steps;
     }
+}
+
+// out = max_i sum_j |E_ij - delta_ij| (one wave per row; non-negative doubles order like their bit patterns)
+__global__ __launch_bounds__(256) void inv_resid_kernel(const double* E, int n, double* out) {
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    double s = 0.0;
+    for (int j = lane; j < n; j += 64) s += fabs(E[(size_t)i * n + j] - (i == j ? 1.0 : 0.0));
+    s = wave_sum(s);
+    if (!(s == s)) s = 1e300;
+    if (lane == 0) atomicMax(reinterpret_cast<unsigned long long*>(out), (unsigned long long)__double_as_longlong(s));
 }
 
 }  // namespace
@@ -586,7 +638,17 @@ int mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double*
     double* Gram = CH + (size_t)m * n;
     rc = launch_gemm_nt(s.Cs, n, s.Hi, n, CH, n, m, n, n, 1.0, 0.0, st);          // CH = Cs Hi   (Hi symmetric)
     if (rc != MPCQP_OK) return rc;
-    return launch_gemm_nt(CH, n, s.Cs, n, Gram, m, m, m, n, 1.0, 0.0, st);          // Gram = CH Cs'
+    rc = launch_gemm_nt(CH, n, s.Cs, n, Gram, m, m, m, n, 1.0, 0.0, st);            // Gram = CH Cs'
+    if (rc != MPCQP_OK) return rc;
+    // eps = |I - Ps Hi|_inf into the third entry of QP 0's W block (beside sigma and the status): what the solve's tail
+    // needs to certify stationarity without a matvec.  The product goes to QP 0's T block, free once the inverse exists
+    double* W0 = shared_ws + (size_t)2 * n * n;
+    double* E = W0 + (size_t)n * n;
+    rc = launch_gemm_nt(s.Ps, n, s.Hi, n, E, n, n, n, n, 1.0, 0.0, st);
+    if (rc != MPCQP_OK) return rc;
+    if (hipMemsetAsync(W0 + 2, 0, sizeof(double), st) != hipSuccess) return MPCQP_EHIP;
+    hipLaunchKernelGGL(inv_resid_kernel, dim3(ceil_div(n, 4)), dim3(256), 0, st, E, n, W0 + 2);
+    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
 }
 
 struct MpcMaps { const double *x0, *F, *f0, *E, *h0; int nx; };

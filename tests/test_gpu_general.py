@@ -224,3 +224,54 @@ def test_blocked_shared_setup_matches_numpy(n, m, p):
     assert rc == 0
     torch.cuda.synchronize()
     assert np.linalg.eigvalsh(P2).min() < 0 and ws[2 * nn + 1].item() == 3.0
+
+
+@pytest.mark.parametrize("cond", [1e2, 1e9])
+def test_rows_kernel_tail_refines_when_the_inverse_is_not_accurate_enough(cond):
+    """The constraint-space kernel certifies optimality of (x, lam) from |I - Ps Hi|_inf (computed by the set-up) and skips
+    its refinement when that bound is at rounding level (cond 1e2).  With an ill-conditioned Hessian (cond 1e9 AFTER the
+    Jacobi scaling) the bound fails and the refinement round with Ps / Cs themselves has to deliver the answer: both cases
+    through the C-ABI (mpcqp_rows_setup / mpcqp_rows_solve) against the oracle."""
+    import ctypes as C
+    import torch
+    from mpc_amd import _lib
+    from oracle.qp_oracle import solve_qp
+    lib = _lib.load()
+    rng = np.random.default_rng(17)
+    n, m, B = 48, 70, 6
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    P = Qo @ np.diag(np.logspace(0, np.log10(cond), n)) @ Qo.T
+    P = 0.5 * (P + P.T)
+    G = rng.standard_normal((m, n))
+    q = rng.standard_normal((B, n)) * 3.0
+    h = rng.uniform(0.05, 0.5, (B, m))
+    dev = torch.device("cuda:0")
+    t = lambda a, dt=torch.float64: torch.as_tensor(a, dtype=dt, device=dev).contiguous()
+    per = C.c_long(0)
+    nsh = lib.mpcqp_rows_workspace(n, m, C.byref(per))
+    sh = torch.zeros(nsh, dtype=torch.float64, device=dev)
+    iw = torch.zeros(n, dtype=torch.int32, device=dev)
+    inst = torch.zeros(B * per.value, dtype=torch.float64, device=dev)
+    Pt, Gt, qt, ht = t(P), t(G), t(q), t(h)
+    x = torch.zeros((B, n), dtype=torch.float64, device=dev); z = torch.zeros((B, m), dtype=torch.float64, device=dev)
+    obj = torch.zeros(B, dtype=torch.float64, device=dev)
+    st = torch.full((B,), -1, dtype=torch.int32, device=dev); it = torch.zeros(B, dtype=torch.int32, device=dev)
+    ptr = lambda a: C.c_void_p(a.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.mpcqp_rows_setup(0, n, m, ptr(Pt), ptr(Gt), ptr(sh), ptr(iw), stream) == 0
+    assert lib.mpcqp_rows_solve(0, B, n, m, ptr(qt), ptr(ht), ptr(x), ptr(z), ptr(obj), ptr(st), ptr(it), ptr(sh), ptr(inst),
+                                stream) == 0
+    torch.cuda.synchronize()
+    eps = sh[2 * n * n + 2].item()                   # |I - Ps Hi|_inf, beside sigma and the set-up status
+    assert (eps < 1e-12) == (cond < 1e5), eps        # which branch of the tail this case exercises
+    xs, zs, os_, ss = x.cpu().numpy(), z.cpu().numpy(), obj.cpu().numpy(), st.cpu().numpy()
+    nact = 0
+    for i in range(B):
+        s = solve_qp(P, q[i], G, h[i])
+        assert s["status"] == "optimal" and ss[i] == 0, i
+        assert np.abs(xs[i] - s["x"]).max() <= 1e-6 * max(1.0, np.abs(s["x"]).max()), i
+        assert abs(os_[i] - s["primal objective"]) <= 1e-8 * max(abs(s["primal objective"]), 1e-12), i
+        g = P @ xs[i] + q[i] + G.T @ zs[i]
+        assert np.abs(g).max() <= 1e-8 * max(1.0, np.abs(q[i]).max()), i
+        nact += int((zs[i] > 0).sum())
+    assert nact >= B
