@@ -376,17 +376,24 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         k = rows_rebuild(p.Gram, m, L, act, lam, k, &sflag);
     }
 
+    // the scan for the most violated row rides on the residual update of a full step (fbest, fbi: this thread's candidate
+    // among the rows it has just rewritten), so only the first one reads the residuals for its own sake
+    bool fused = false;
+    double fbest = 0.0; int fbi = -1;
     while (status == 0) {
         // the most violated row that is not in the active set
         double best = 0.0; int bi = -1;
-        for (int r = tid; r < m; r += RT) {
-            const double v = res[r];
-            if (v > 1e-12 * fmax(1.0, fabs(cs[r])) && (bi < 0 || v > best)) {
-                bool member = false;
-                for (int a = 0; a < k; ++a) member |= act[a] == r;
-                if (!member) { best = v; bi = r; }
+        if (fused) { best = fbest; bi = fbi; }
+        else
+            for (int r = tid; r < m; r += RT) {
+                const double v = res[r];
+                if (v > 1e-12 * fmax(1.0, fabs(cs[r])) && (bi < 0 || v > best)) {
+                    bool member = false;
+                    for (int a = 0; a < k; ++a) member |= act[a] == r;
+                    if (!member) { best = v; bi = r; }
+                }
             }
-        }
+        fused = false;
         double v0; int pp;
         blk_argmax(best, bi, red, redi, v0, pp);
         TICK(t_arg)
@@ -428,7 +435,10 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
             if (jb < 0 && dep) { status = 2; break; }           // no step possible: infeasible
             const bool full = !dep && t2 <= tr;
             const double t = full ? t2 : tr;
-            if (!dep)
+            if (!dep) {
+                // after a full step with room for p the active set is act + {p}: the candidates of the next scan
+                const bool scan = full && k < KL;
+                fbest = 0.0; fbi = -1;
                 for (int r0 = 0; r0 < m; r0 += 8 * RT) {
                     double sv[8]; int r[8];
 #pragma unroll
@@ -440,8 +450,19 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                         for (int e = 0; e < 8; ++e) if (r[e] < m) sv[e] -= cf * ga[r[e]];
                     }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) if (r[e] < m) res[r[e]] -= t * sv[e];
+                    for (int e = 0; e < 8; ++e)
+                        if (r[e] < m) {
+                            const double v = res[r[e]] - t * sv[e];
+                            res[r[e]] = v;
+                            if (scan && v > 1e-12 * fmax(1.0, fabs(cs[r[e]])) && (fbi < 0 || v > fbest) && r[e] != pp) {
+                                bool member = false;
+                                for (int a = 0; a < k; ++a) member |= act[a] == r[e];
+                                if (!member) { fbest = v; fbi = r[e]; }
+                            }
+                        }
                 }
+                fused = scan;
+            }
             __syncthreads();
             TICK(t_upd)
             if (wave == 0) {
