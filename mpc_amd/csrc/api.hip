@@ -183,7 +183,7 @@ int mpcqp_assemble(mpcqp_handle h, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->A || !h->Q) { h->err = "assemble: set_model and set_cost first"; return MPCQP_ESTATE; }
     HIPCHK(h, hipSetDevice(h->dev));
-    TRY(launch_assemble(h, static_cast<hipStream_t>(stream)));
+    TRY(launch_assemble(h, static_cast<hipStream_t>(stream), h->g_xmin || h->g_C));
     h->assembled = true; h->factored = false;
     return MPCQP_OK;
 }
@@ -278,7 +278,10 @@ int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, v
         case 0: src = h->H + model * n * n; len = n * n; break;
         case 1: src = h->F + model * n * nx; len = n * nx; break;
         case 2: src = h->f0 + model * n; len = n; break;
-        case 3: src = h->Gam + model * p * n; len = p * n; break;
+        case 3:
+            if (!h->assembled) { h->err = "get: assemble first"; return MPCQP_ESTATE; }
+            if (!h->gam_valid) { HIPCHK(h, hipSetDevice(h->dev)); TRY(launch_assemble(h, static_cast<hipStream_t>(stream), true)); }
+            src = h->Gam + model * p * n; len = p * n; break;
         case 4: src = h->Phi + model * p * nx; len = p * nx; break;
         case 5: src = h->Hs + (h->dims.n_models > 1 ? model * n * n : 0); len = n * n; break;
         case 6: src = h->M; len = n * n; break;

@@ -223,9 +223,218 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     }
 }
 
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- one model per instance, small nx: H, F, f0 WITHOUT the prediction matrices ----------------------------------------
+// H = Gamma' Qbar Gamma + Rbar has the structure of the dynamics: with Psi(k, j) = A_k ... A_{j+1} and
+//     P_k = Q_k + A_{k+1}' P_{k+1} A_{k+1}     (backwards from P_{N-1} = terminal weight)
+// the block (i, j), i <= j, is  B_i' Psi(j, i)' P_j B_j  (+ R on the diagonal): for every column j one chain
+//     V = P_j B_j;   for i = j .. 0:   H_ij = B_i' V,   V <- A_i' V.
+// Likewise F_i = B_i' S_i with S_k = Q_k Phi_k + A_{k+1}' S_{k+1} and f0_i = -B_i' s_i - R uref_i with
+// s_k = Q_k xref_k + A_{k+1}' s_{k+1}.  O(N^2) small products instead of the (N nx) x n x n contraction, and neither Gamma nor
+// Qbar Gamma is ever written: the 440 MB that kernel moved per step of BASELINE configs[3] (8,192 models) and 0.44 of the
+// 0.89 ms the step took.  One WAVE per model: the model, Phi_k and P_k live in LDS, lane (j, c) owns column j nu + c of H
+// with its V column in registers.  Same quantities as assemble_kernel up to the order of summation.
+// (Reference: the same cost and prediction model, LaunchPlannerQPFormulation.py:49-89,130-162; HelperFuncs.py:6-11.)
+template <int NX>
+__global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int XX = NX * NX;
+    const int lane = threadIdx.x, m = blockIdx.x;
+    const int nu = a.nu, N = a.N, n = a.n, nA = a.tv ? N : 1, XU = NX * nu;
+    const double* Am = a.A + (size_t)m * nA * XX;
+    const double* Bm = a.B + (size_t)m * nA * XU;
+    double* Phi = a.Phi + (size_t)m * a.p * NX;
+    double* H = a.H + (size_t)m * n * n;
+    double* F = a.F + (size_t)m * n * NX;
+    double* f0 = a.f0 + (size_t)m * n;
+    double* sA = reinterpret_cast<double*>(smem);       // nA x (NX, NX)
+    double* sB = sA + nA * XX;                          // nA x (NX, nu)
+    double* sQ = sB + nA * XU;                          // Q, terminal P
+    double* sR = sQ + 2 * XX;                           // (nu, nu)
+    double* sPhi = sR + nu * nu;                        // N x (NX, NX): Phi_k = A_k ... A_0
+    double* sP = sPhi + N * XX;                         // N x (NX, NX): P_k
+    double* sS = sP + N * XX;                           // 2 x (NX, NX): S_k, ping-pong
+    double* sT = sS + 2 * XX;                           // (NX, NX): P_{k+1} A_{k+1}
+    double* ss = sT + XX;                               // 2 x NX: s_k, ping-pong
+    for (int i = lane; i < nA * XX; i += 64) sA[i] = Am[i];
+    for (int i = lane; i < nA * XU; i += 64) sB[i] = Bm[i];
+    for (int i = lane; i < XX; i += 64) { sQ[i] = a.Q[i]; sQ[XX + i] = a.P[i]; }
+    for (int i = lane; i < nu * nu; i += 64) sR[i] = a.R[i];
+    wave_sync();
+    const int er = lane / NX, ec = lane % NX;           // lane < XX: element (er, ec) of the NX x NX recursions
+    // ---- forward: Phi_k ------------------------------------------------------------------------------------------------
+    for (int k = 0; k < N; ++k) {
+        const double* Ak = sA + (a.tv ? k * XX : 0);
+        if (lane < XX) {
+            double v;
+            if (k == 0) v = Ak[lane];
+            else {
+                v = 0.0;
+                const double* pk = sPhi + (k - 1) * XX;
+#pragma unroll
+                for (int b = 0; b < NX; ++b) v += Ak[er * NX + b] * pk[b * NX + ec];
+            }
+            sPhi[k * XX + lane] = v;
+            Phi[(size_t)(k * NX + er) * NX + ec] = v;
+        }
+        wave_sync();
+    }
+    // ---- backward: P_k, S_k, s_k; rows of F and f0 of stage k as soon as S_k, s_k exist ------------------------------------
+    const double* xr = a.xref ? a.xref + (size_t)m * a.xref_stride : nullptr;
+    const double* ur = a.uref ? a.uref + (size_t)m * a.uref_stride : nullptr;
+    for (int k = N - 1; k >= 0; --k) {
+        const double* Qk = (k == N - 1) ? sQ + XX : sQ;
+        const double* A1 = sA + (a.tv ? (k + 1) * XX : 0);          // A_{k+1} (k < N-1 only)
+        double* Sk = sS + (k & 1) * XX; const double* S1 = sS + ((k + 1) & 1) * XX;
+        double* sk = ss + (k & 1) * NX; const double* s1 = ss + ((k + 1) & 1) * NX;
+        if (k < N - 1 && lane < XX) {
+            double t = 0.0;
+            const double* P1 = sP + (k + 1) * XX;
+#pragma unroll
+            for (int b = 0; b < NX; ++b) t += P1[er * NX + b] * A1[b * NX + ec];
+            sT[lane] = t;
+        }
+        wave_sync();
+        if (lane < XX) {
+            double pv = Qk[lane], sv = 0.0;
+            const double* pk = sPhi + k * XX;
+#pragma unroll
+            for (int b = 0; b < NX; ++b) sv += Qk[er * NX + b] * pk[b * NX + ec];
+            if (k < N - 1) {
+#pragma unroll
+                for (int b = 0; b < NX; ++b) { pv += A1[b * NX + er] * sT[b * NX + ec]; sv += A1[b * NX + er] * S1[b * NX + ec]; }
+            }
+            sP[k * XX + lane] = pv;
+            Sk[lane] = sv;
+        }
+        if (lane < NX) {
+            double v = 0.0;
+            if (xr) {
+#pragma unroll
+                for (int b = 0; b < NX; ++b) v += Qk[lane * NX + b] * xr[k * NX + b];
+            }
+            if (k < N - 1) {
+#pragma unroll
+                for (int b = 0; b < NX; ++b) v += A1[b * NX + lane] * s1[b];
+            }
+            sk[lane] = v;
+        }
+        wave_sync();
+        const double* Bk = sB + (a.tv ? k * XU : 0);
+        for (int e = lane; e < nu * NX; e += 64) {                  // F rows of stage k: B_k' S_k
+            const int r = e / NX, c = e % NX;
+            double v = 0.0;
+#pragma unroll
+            for (int b = 0; b < NX; ++b) v += Bk[b * nu + r] * Sk[b * NX + c];
+            F[(size_t)(k * nu + r) * NX + c] = v;
+        }
+        for (int r = lane; r < nu; r += 64) {                       // f0 rows of stage k
+            double v = 0.0;
+#pragma unroll
+            for (int b = 0; b < NX; ++b) v -= Bk[b * nu + r] * sk[b];
+            if (ur) for (int j = 0; j < nu; ++j) v -= sR[r * nu + j] * ur[k * nu + j];
+            f0[k * nu + r] = v;
+        }
+    }
+    wave_sync();
+    // ---- columns of H -----------------------------------------------------------------------------------------------------
+    for (int col = lane; col < n; col += 64) {
+        const int j = col / nu, c = col - j * nu;
+        double v[NX];
+        {
+            const double* Pj = sP + j * XX;
+            const double* Bj = sB + (a.tv ? j * XU : 0);
+#pragma unroll
+            for (int r = 0; r < NX; ++r) {
+                double t = 0.0;
+#pragma unroll
+                for (int b = 0; b < NX; ++b) t += Pj[r * NX + b] * Bj[b * nu + c];
+                v[r] = t;
+            }
+        }
+        for (int i = j; i >= 0; --i) {
+            const double* Bi = sB + (a.tv ? i * XU : 0);
+            const double* Ai = sA + (a.tv ? i * XX : 0);
+            // the diagonal block is written from its upper triangle only, so that every entry of H has one writer and the
+            // matrix is exactly symmetric
+            const int rmax = i == j ? c : nu - 1;
+            for (int r = 0; r <= rmax; ++r) {
+                double hv = 0.0;
+#pragma unroll
+                for (int b = 0; b < NX; ++b) hv += Bi[b * nu + r] * v[b];
+                if (i == j) hv += sR[r * nu + c];
+                const int row = i * nu + r;
+                H[(size_t)row * n + col] = hv;
+                H[(size_t)col * n + row] = hv;
+            }
+            if (i > 0) {
+                double w[NX];
+#pragma unroll
+                for (int r = 0; r < NX; ++r) {
+                    double t = 0.0;
+#pragma unroll
+                    for (int b = 0; b < NX; ++b) t += Ai[b * NX + r] * v[b];
+                    w[r] = t;
+                }
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v[r] = w[r];
+            }
+        }
+    }
+}
+
+template <int NX>
+int launch_assemble_wave_nx(mpcqp_handle h, const AsmParams& a, size_t lds, hipStream_t st) {
+    hipError_t e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&assemble_wave_kernel<NX>), lds);
+    if (e != hipSuccess) { h->err = hipGetErrorString(e); return MPCQP_EHIP; }
+    hipLaunchKernelGGL(assemble_wave_kernel<NX>, dim3(h->dims.n_models), dim3(64), lds, st, a);
+    return MPCQP_OK;
+}
+
 }  // namespace
 
-int launch_assemble(mpcqp_handle h, hipStream_t st) {
+// What the condensed QP needs without the prediction matrices (one model per instance, small nx): -1 if the shape is not
+// covered, else the launch's return code
+static int launch_assemble_wave(mpcqp_handle h, hipStream_t st) {
+    const int nx = h->dims.nx, nu = h->dims.nu, N = h->dims.N;
+    if (h->dims.n_models < 2 || nx > 8) return -1;
+    const int nA = h->dims.time_varying ? N : 1, XX = nx * nx;
+    const size_t lds = ((size_t)nA * (XX + nx * nu) + 2 * XX + nu * nu + 2 * (size_t)N * XX + 3 * XX + 2 * nx) * sizeof(double);
+    if (lds > 40 * 1024) return -1;
+    AsmParams a;
+    a.A = h->A; a.B = h->B; a.Q = h->Q; a.R = h->R; a.P = h->P; a.xref = h->xref; a.uref = h->uref;
+    a.xref_stride = h->xref_stride; a.uref_stride = h->uref_stride;
+    a.Gam = nullptr; a.QG = nullptr; a.Phi = h->Phi; a.H = h->H; a.F = h->F; a.f0 = h->f0;
+    a.nx = nx; a.nu = nu; a.N = N; a.n = h->n; a.p = h->p; a.tv = h->dims.time_varying;
+    a.rows_in_lds = 0; a.ab_in_lds = 0; a.phases = 0;
+    int rc = MPCQP_OK;
+    switch (nx) {
+        case 1: rc = launch_assemble_wave_nx<1>(h, a, lds, st); break;
+        case 2: rc = launch_assemble_wave_nx<2>(h, a, lds, st); break;
+        case 3: rc = launch_assemble_wave_nx<3>(h, a, lds, st); break;
+        case 4: rc = launch_assemble_wave_nx<4>(h, a, lds, st); break;
+        case 5: rc = launch_assemble_wave_nx<5>(h, a, lds, st); break;
+        case 6: rc = launch_assemble_wave_nx<6>(h, a, lds, st); break;
+        case 7: rc = launch_assemble_wave_nx<7>(h, a, lds, st); break;
+        default: rc = launch_assemble_wave_nx<8>(h, a, lds, st); break;
+    }
+    if (rc != MPCQP_OK) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { h->err = std::string("assemble (wave) launch: ") + hipGetErrorString(e); return MPCQP_EHIP; }
+    return MPCQP_OK;
+}
+
+// with_gamma: the caller needs Gamma / Qbar Gamma in memory (state or polytopic rows, mpcqp_get of Gamma)
+int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma) {
+    if (!with_gamma) {
+        const int rc = launch_assemble_wave(h, st);
+        if (rc >= 0) { if (rc == MPCQP_OK) h->gam_valid = false; return rc; }
+    }
+    h->gam_valid = true;
     AsmParams a;
     a.A = h->A; a.B = h->B; a.Q = h->Q; a.R = h->R; a.P = h->P; a.xref = h->xref; a.uref = h->uref;
     a.xref_stride = h->xref_stride; a.uref_stride = h->uref_stride;

@@ -34,6 +34,7 @@ struct mpcqp_handle_s {
     double *H = nullptr, *F = nullptr, *f0 = nullptr;       // (n,n) (n,nx) (n)
     // shared-model solver data (model 0)
     double *d = nullptr, *Hs = nullptr, *M = nullptr, *Hi = nullptr, *W1 = nullptr, *W2 = nullptr;
+    bool gam_valid = false;        // Gam / QG hold the prediction matrices of the current model (the per-instance fast assembly skips them)
     double *facL = nullptr, *facBlk = nullptr;     // shared model: scratch of the blocked inverses (blocked_setup.hip)
     double *Fs1 = nullptr;      // (n, nx+1): [Fs | f0s]   qs = Fs1 [x0;1]
     double *Cq = nullptr;       // (nx+1, nx+1): Fs1' Ku1 (shared model): qs'x_unc = [x0;1]' Cq [x0;1]
@@ -82,7 +83,7 @@ struct mpcqp_handle_s {
 hipError_t ensure_dyn_lds(int device, const void* kernel, size_t bytes);
 
 // ---- launchers implemented in the kernel translation units ----------------------
-int launch_assemble(mpcqp_handle h, hipStream_t st);
+int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma);
 int launch_factor(mpcqp_handle h, double rho, hipStream_t st);
 int launch_factor_batch(mpcqp_handle h, hipStream_t st);
 int launch_admm_shared_box(mpcqp_handle h, const double* x0, int B, const mpcqp_solve_opts& o, hipStream_t st);

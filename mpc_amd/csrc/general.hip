@@ -179,6 +179,8 @@ int factor_general(mpcqp_handle h, hipStream_t st) {
     const int nc = h->g_C ? h->g_nc : 0;
     const long mfull = 2L * n + (xbox ? 2L * p : 0) + 2L * N * nc;
     general_free(h);
+    // the rows are built from Gamma: assemble it if the last assembly took the route that skips it
+    if (!h->gam_valid && (xbox || nc > 0)) { const int ra = launch_assemble(h, st, true); if (ra != MPCQP_OK) return ra; }
     double* hf = nullptr; int* pos = nullptr;
     auto cleanup = [&]() { for (void* q : {(void*)hf, (void*)pos}) if (q) (void)hipFree(q); };
     int rc = grow(h, &hf, (size_t)mfull);

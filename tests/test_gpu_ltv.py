@@ -196,3 +196,45 @@ def test_per_instance_factor_tile_counts(N, nx, nu):
         s = _oracle_instance(A[i], Bm[i], Q, R, P, None, None, lb[i], ub[i], x0[i])
         assert _rel(U[i], s["x"]) <= PRIMAL_RTOL, i
         assert abs(obj[i] - s["primal objective"]) <= OBJ_RTOL * max(abs(s["primal objective"]), 1e-300), i
+
+
+@pytest.mark.parametrize("nx,nu,N,tv", [(4, 2, 20, True), (3, 3, 7, True), (5, 1, 33, False), (8, 2, 9, True), (1, 1, 5, True)])
+def test_structured_assembly_matches_the_prediction_matrix_form(nx, nu, N, tv):
+    """One model per instance with nx <= 8 is assembled WITHOUT the prediction matrices (assemble_wave_kernel: the backward
+    recursion P_k = Q_k + A_{k+1}' P_{k+1} A_{k+1} and one chain per column of H).  H, F, f0 must be those of
+    H = Gamma' Qbar Gamma + Rbar, F = Gamma' Qbar Phi, f0 = -Gamma' Qbar x_ref - Rbar u_ref (the restatement of
+    LaunchPlannerQPFormulation.py:49-89,130-162), per model, with references per model; Gamma itself is still there for
+    whoever asks for it."""
+    import torch
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    rng = np.random.default_rng(100 * nx + N)
+    nb = 5
+    shape_a = (nb, N if tv else 1, nx, nx)         # (batch, 1, ...): one time-invariant model per instance
+    shape_b = (nb, N if tv else 1, nx, nu)
+    A = 0.8 * np.eye(nx) + 0.3 * rng.standard_normal(shape_a)
+    Bm = rng.standard_normal(shape_b)
+    Mq = rng.standard_normal((nx, nx)); Q = Mq @ Mq.T + 0.1 * np.eye(nx)
+    Mp = rng.standard_normal((nx, nx)); P = Mp @ Mp.T + 0.5 * np.eye(nx)
+    Mr = rng.standard_normal((nu, nu)); R = Mr @ Mr.T + 0.2 * np.eye(nu)
+    xr = rng.standard_normal((nb, N, nx)); ur = rng.standard_normal((nb, N, nu))
+    pl = Planner(nx, nu, N).set_model(A, Bm).set_cost(Q, R, P, x_ref=xr, u_ref=ur)
+    pl.set_constraints(-np.ones(nu), np.ones(nu)).setup()
+    Ai = lambda i: A[i] if tv else A[i, 0]
+    Bi = lambda i: Bm[i] if tv else Bm[i, 0]
+    for i in range(nb):
+        prob = dict(N=N, nx=nx, nu=nu, A=Ai(i), B=Bi(i), Q=Q, R=R, P=P)
+        H, F, f0 = mo.condense(prob, x_ref=xr[i], u_ref=ur[i])
+        Gam, Phi = mo.rollout_matrices(Ai(i), Bi(i), N)
+        Hd = pl.get("H", model=i).cpu().numpy()
+        assert np.array_equal(Hd, Hd.T)
+        assert np.abs(Hd - H).max() <= 1e-12 * np.abs(H).max(), i
+        assert np.abs(pl.get("F", model=i).cpu().numpy() - F).max() <= 1e-12 * max(1.0, np.abs(F).max()), i
+        assert np.abs(pl.get("f0", model=i).cpu().numpy() - f0).max() <= 1e-12 * max(1.0, np.abs(f0).max()), i
+        assert np.abs(pl.get("Phi", model=i).cpu().numpy() - Phi).max() <= 1e-12 * max(1.0, np.abs(Phi).max()), i
+    # Gamma on request (the first call runs the prediction-matrix assembly)
+    i = nb - 1
+    Gam, _ = mo.rollout_matrices(Ai(i), Bi(i), N)
+    assert np.abs(pl.get("Gamma", model=i).cpu().numpy() - Gam).max() <= 1e-12 * max(1.0, np.abs(Gam).max())
+    H, _, _ = mo.condense(dict(N=N, nx=nx, nu=nu, A=Ai(i), B=Bi(i), Q=Q, R=R, P=P))
+    assert np.abs(pl.get("H", model=i).cpu().numpy() - H).max() <= 1e-12 * np.abs(H).max()
