@@ -223,8 +223,9 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     }
 }
 
+// orders the LDS traffic of one wave only: the global stores of a step (rows of Phi, F, f0) stay in flight
 __device__ __forceinline__ void wave_sync() {
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
 }
 
@@ -238,6 +239,11 @@ __device__ __forceinline__ void wave_sync() {
 // Qbar Gamma is ever written: the 440 MB that kernel moved per step of BASELINE configs[3] (8,192 models) and 0.44 of the
 // 0.89 ms the step took.  One WAVE per model: the model, Phi_k and P_k live in LDS, lane (j, c) owns column j nu + c of H
 // with its V column in registers.  Same quantities as assemble_kernel up to the order of summation.
+// Measured for 8,192 bicycle models (nx 4, nu 2, N 20): 0.14 ms against 0.44 ms.  It is bound by instruction issue, not by
+// memory or latency (~5,000 wave instructions per model, 16 of 64 lanes busy in the recursions, the triangle of chains half
+// masked, 8 waves per SIMD in turn): staging H through LDS for whole-row stores (0.21 ms: LDS costs occupancy), the
+// references in LDS instead of loads inside the chain, and dropping the mirrored stores (0.137 ms) all left it where it is.
+// What would help is several models per wave, which the 10 KB of LDS per model do not allow at a useful occupancy.
 // (Reference: the same cost and prediction model, LaunchPlannerQPFormulation.py:49-89,130-162; HelperFuncs.py:6-11.)
 template <int NX>
 __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
@@ -260,6 +266,12 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
     double* sS = sP + N * XX;                           // 2 x (NX, NX): S_k, ping-pong
     double* sT = sS + 2 * XX;                           // (NX, NX): P_{k+1} A_{k+1}
     double* ss = sT + XX;                               // 2 x NX: s_k, ping-pong
+    double* sxr = ss + 2 * NX;                          // (N, NX), (N, nu): the model's references -- nothing inside the
+    double* sur = sxr + N * NX;                         // backward chain may wait on global memory
+    const double* xr = a.xref ? a.xref + (size_t)m * a.xref_stride : nullptr;
+    const double* ur = a.uref ? a.uref + (size_t)m * a.uref_stride : nullptr;
+    for (int i = lane; i < N * NX; i += 64) sxr[i] = xr ? xr[i] : 0.0;
+    for (int i = lane; i < N * nu; i += 64) sur[i] = ur ? ur[i] : 0.0;
     for (int i = lane; i < nA * XX; i += 64) sA[i] = Am[i];
     for (int i = lane; i < nA * XU; i += 64) sB[i] = Bm[i];
     for (int i = lane; i < XX; i += 64) { sQ[i] = a.Q[i]; sQ[XX + i] = a.P[i]; }
@@ -284,8 +296,6 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
         wave_sync();
     }
     // ---- backward: P_k, S_k, s_k; rows of F and f0 of stage k as soon as S_k, s_k exist ------------------------------------
-    const double* xr = a.xref ? a.xref + (size_t)m * a.xref_stride : nullptr;
-    const double* ur = a.uref ? a.uref + (size_t)m * a.uref_stride : nullptr;
     for (int k = N - 1; k >= 0; --k) {
         const double* Qk = (k == N - 1) ? sQ + XX : sQ;
         const double* A1 = sA + (a.tv ? (k + 1) * XX : 0);          // A_{k+1} (k < N-1 only)
@@ -313,10 +323,8 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
         }
         if (lane < NX) {
             double v = 0.0;
-            if (xr) {
 #pragma unroll
-                for (int b = 0; b < NX; ++b) v += Qk[lane * NX + b] * xr[k * NX + b];
-            }
+            for (int b = 0; b < NX; ++b) v += Qk[lane * NX + b] * sxr[k * NX + b];
             if (k < N - 1) {
 #pragma unroll
                 for (int b = 0; b < NX; ++b) v += A1[b * NX + lane] * s1[b];
@@ -336,7 +344,7 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
             double v = 0.0;
 #pragma unroll
             for (int b = 0; b < NX; ++b) v -= Bk[b * nu + r] * sk[b];
-            if (ur) for (int j = 0; j < nu; ++j) v -= sR[r * nu + j] * ur[k * nu + j];
+            for (int j = 0; j < nu; ++j) v -= sR[r * nu + j] * sur[k * nu + j];
             f0[k * nu + r] = v;
         }
     }
@@ -403,7 +411,8 @@ static int launch_assemble_wave(mpcqp_handle h, hipStream_t st) {
     const int nx = h->dims.nx, nu = h->dims.nu, N = h->dims.N;
     if (h->dims.n_models < 2 || nx > 8) return -1;
     const int nA = h->dims.time_varying ? N : 1, XX = nx * nx;
-    const size_t lds = ((size_t)nA * (XX + nx * nu) + 2 * XX + nu * nu + 2 * (size_t)N * XX + 3 * XX + 2 * nx) * sizeof(double);
+    const size_t lds = ((size_t)nA * (XX + nx * nu) + 2 * XX + nu * nu + 2 * (size_t)N * XX + 3 * XX + 2 * nx +
+                        (size_t)N * (nx + nu)) * sizeof(double);
     if (lds > 40 * 1024) return -1;
     AsmParams a;
     a.A = h->A; a.B = h->B; a.Q = h->Q; a.R = h->R; a.P = h->P; a.xref = h->xref; a.uref = h->uref;
