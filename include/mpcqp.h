@@ -279,6 +279,14 @@ int mpcqp_remove_null_rows(int device_id, int rows, int cols, const double* J, c
 int mpcqp_ltv_bicycle(int device_id, int batch, int N, double dt, double L, const double* x, const double* plan,
                       const double* x_ref, const double* u_min, const double* u_max, double* xbar, double* A,
                       double* B, double* xref_dev, double* uref_dev, double* lb, double* ub, void* stream);
+/* after the solve of that QP: plan = plan_in + dU; u0 (batch, 2) = its first stage (the applied input); plan_out = the plan
+ * moved up one stage with the last one repeated (may not alias plan_in); with x, x_next (batch, 4; both or neither) the
+ * bicycle itself one step on under u0.  One launch for the apply / shift of a receding-horizon step. */
+int mpcqp_ltv_bicycle_apply(int device_id, int batch, int N, double dt, double L, const double* plan_in, const double* dU,
+                            double* plan_out, double* u0, const double* x, double* x_next, void* stream);
+/* x_next = f(x, u): the plant of the closed loop (x, x_next (batch, 4); u (batch, 2)) */
+int mpcqp_ltv_bicycle_step(int device_id, int batch, double dt, double L, const double* x, const double* u, double* x_next,
+                           void* stream);
 
 #ifdef __cplusplus
 }

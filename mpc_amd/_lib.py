@@ -64,6 +64,8 @@ SYMBOLS = [
     ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),
     ("mpcqp_remove_null_rows", C.c_int, [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_double] + [C.c_void_p] * 5),
     ("mpcqp_ltv_bicycle", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 13),
+    ("mpcqp_ltv_bicycle_apply", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 7),
+    ("mpcqp_ltv_bicycle_step", C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 4),
     ("mpcqp_solve_dense_strided", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_long] * 6 + [C.c_void_p] * 8 + [C.c_void_p]),
     ("mpcqp_default_dense_opts", None, [C.POINTER(DenseOpts)]),
     ("mpcqp_solve_dense_opts", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_long] * 6 + [C.c_void_p] * 8 +

@@ -22,6 +22,19 @@ class Bicycle:
         self.L, self.dt = float(L), float(dt)
 
     def step(self, x, u):
+        if x.is_cuda and x.dim() == 2 and x.dtype == torch.float64 and u.dtype == torch.float64:
+            # the plant of the closed loop in one launch (the tensor form below is a dozen element-wise kernels)
+            import ctypes as C
+            from . import _lib
+            lib = _lib.load()
+            x, u = x.contiguous(), u.contiguous()
+            out = torch.empty_like(x)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            rc = lib.mpcqp_ltv_bicycle_step(x.device.index or 0, x.shape[0], self.dt, self.L, p(x), p(u), p(out),
+                                            C.c_void_p(torch.cuda.current_stream(x.device).cuda_stream))
+            if rc != 0:
+                raise RuntimeError(f"mpcqp_ltv_bicycle_step failed with code {rc}")
+            return out
         px, py, psi, v = x.unbind(-1)
         a, delta = u.unbind(-1)
         dt, L = self.dt, self.L
@@ -60,6 +73,7 @@ class ClosedLoopLTV:
         self._dx0 = None
         self._buf = None            # persistent linearisation buffers (bicycle kernel)
         self._registered = False
+        self._plan2 = None          # the other half of the plan's ping-pong (fused apply / shift)
 
     def nominal(self, x, plan):
         xs = [x]
@@ -149,11 +163,23 @@ class ClosedLoopLTV:
             self._dx0 = torch.zeros((Bn, self.model.nx), dtype=torch.float64, device=self.device)
         dU = pl.solve(self._dx0, warm_start=(warm and not first), **opts)
         self.last = dict(xbar=lin["xbar"], ubar=ubar, A=lin["A"], B=lin["B"], x_ref=x_ref, dU=dU)
-        plan = ubar + dU
-        u0 = plan[:, 0].clone()
-        # shift: drop the applied stage, repeat the last one; the kept multipliers move the same way and the
+        # apply, then shift: drop the applied stage, repeat the last one; the kept multipliers move the same way and the
         # primal state is re-centred (the shifted plan is the origin of the next QP)
-        self.plan = torch.cat((plan[:, 1:], plan[:, -1:]), dim=1).contiguous()
+        if isinstance(self.model, Bicycle) and ubar.is_cuda:
+            import ctypes as C
+            if self._plan2 is None or self._plan2.shape != ubar.shape or self._plan2.data_ptr() == ubar.data_ptr():
+                self._plan2 = torch.empty_like(ubar)
+            u0 = torch.empty((Bn, self.model.nu), dtype=torch.float64, device=self.device)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            rc = pl._lib.mpcqp_ltv_bicycle_apply(self.device.index or 0, Bn, self.N, self.model.dt, self.model.L, p(ubar),
+                                                 p(dU.contiguous()), p(self._plan2), p(u0), None, None, pl._stream())
+            if rc != 0:
+                raise RuntimeError(f"mpcqp_ltv_bicycle_apply failed with code {rc}")
+            self.plan, self._plan2 = self._plan2, ubar       # `last["ubar"]` stays valid until the step after next
+        else:
+            plan = ubar + dU
+            u0 = plan[:, 0].clone()
+            self.plan = torch.cat((plan[:, 1:], plan[:, -1:]), dim=1).contiguous()
         pl.shift().recenter()
         # after the first (synchronous, validated) step the set-up calls no longer wait for the device
         pl.no_sync, pl.check_inputs = True, False
