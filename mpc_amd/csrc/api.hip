@@ -197,7 +197,7 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     // state-box / polytopic rows, or more inputs than the box kernels hold: the general-constraint path (general.hip)
     if (h->g_xmin || h->g_C || h->g_path == 2 || !admm_shared_box_supported(h->NT, h->S)) return factor_general(h, st);
     if (h->general) general_free(h);
-    if (h->dims.n_models > 1) TRY(launch_factor_batch(h, st));      // one model per instance: active-set path only
+    if (h->dims.n_models > 1) TRY(launch_factor_batch(h, st, !(opts && opts->no_sync)));      // one model per instance: active-set path only
     else TRY(launch_factor(h, opts ? opts->rho : 0.0, st));
     if (opts && opts->no_sync && (h->dims.n_models > 1 || opts->rho > 0.0)) {
         // closed-loop use: no host round trip.  A failed factorisation is then reported per instance by the

@@ -85,7 +85,7 @@ hipError_t ensure_dyn_lds(int device, const void* kernel, size_t bytes);
 // ---- launchers implemented in the kernel translation units ----------------------
 int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma);
 int launch_factor(mpcqp_handle h, double rho, hipStream_t st);
-int launch_factor_batch(mpcqp_handle h, hipStream_t st);
+int launch_factor_batch(mpcqp_handle h, hipStream_t st, bool probe);
 int launch_admm_shared_box(mpcqp_handle h, const double* x0, int B, const mpcqp_solve_opts& o, hipStream_t st);
 int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
                       const mpcqp_solve_opts& o, hipStream_t st);

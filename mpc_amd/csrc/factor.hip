@@ -195,7 +195,7 @@ struct FacBatchParams {
     const double *H, *F, *f0, *umin, *umax;
     double *d, *Hs, *Hi, *W1, *W2, *Fs1, *Ku1, *FsT, *KuT, *lbs, *ubs, *rho_dev;
     int *flag, *mflag;                  // any model failed / per model
-    int n, nx, nu, NP, per_stage, use_lds;
+    int n, nx, nu, NP, per_stage, use_lds, probe;
     long bnd_stride;
 };
 
@@ -383,17 +383,36 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
 #ifdef FAC_PROF
     long long tk0 = wall_clock64(), t_ld = 0, t_chol = 0, t_inv = 0, t_hi = 0, t_ku = 0, t_pr = 0;
 #endif
+    // raw H into LDS (identity on the padding): the matrix as one flat array, 16 coalesced loads in flight per lane before the
+    // first LDS write waits for one (row by row the 40 loads of a bicycle model came back in 5 rounds of memory latency)
+    {
+        const int tot = n * n;
+        for (int base = 0; base < tot; base += 16 * 64) {
+            double hv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { const int idx = base + 64 * u + i; hv[u] = idx < tot ? H[idx] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const int idx = base + 64 * u + i;
+                if (idx < tot) { const int r = idx / n; S[r * LDW + (idx - r * n)] = hv[u]; }
+            }
+        }
+    }
+    for (int r = 0; r < NPD; ++r)
+        if (i < NPD && (r >= n || i >= n)) S[r * LDW + i] = (r == i) ? 1.0 : 0.0;
+    wv_sync();
     if (in) {
-        const double hii = H[(size_t)i * n + i];
+        const double hii = S[i * LDW + i];
         if (!(hii > 0.0)) bad = true; else di = 1.0 / sqrt(hii);
         sd[i] = di;
     }
-    // raw H into LDS with coalesced loads (identity on the padding), then symmetrise and scale in place: at step r the
-    // lanes i >= r own the pair (r,i), (i,r)
-#pragma unroll 8
-    for (int r = 0; r < n; ++r) if (in) S[r * LDW + i] = H[(size_t)r * n + i];
-    for (int r = 0; r < NPD; ++r)
-        if (i < NPD && (r >= n || i >= n)) S[r * LDW + i] = (r == i) ? 1.0 : 0.0;
+    // [Fs | f0s] = d [F | f0]: read now, so that the loads overlap the factorisation; needed again for Ku at the end
+    double* __restrict__ Fs1 = f.Fs1 + m * n * nx1;
+    if (in)
+        for (int c = 0; c < nx1; ++c) {
+            const double v = di * (c < nx ? F[(size_t)i * nx + c] : f0[i]);
+            sF[i * nx1 + c] = v; Fs1[(size_t)i * nx1 + c] = v;
+        }
     wv_sync();
     for (int r = 0; r < n; ++r) {
         if (in && i >= r) {
@@ -515,28 +534,31 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     { long long tk = wall_clock64(); t_hi += tk - tk0; tk0 = tk; }
 #endif
     // [Fs | f0s] and [Ku | ku], also transposed (nx+1, NP)
-    double* __restrict__ Fs1 = f.Fs1 + m * n * nx1;
     double* __restrict__ Ku1 = f.Ku1 + m * n * nx1;
     double* __restrict__ FsT = f.FsT + m * NP * nx1;
     double* __restrict__ KuT = f.KuT + m * NP * nx1;
-    if (in)
-        for (int c = 0; c < nx1; ++c) {
-            const double v = di * (c < nx ? F[(size_t)i * nx + c] : f0[i]);
-            sF[i * nx1 + c] = v; Fs1[(size_t)i * nx1 + c] = v;
-        }
-    wv_sync();
-    for (int c = 0; c < nx1; ++c) {
-        double su = 0.0;
+    // Ku = -Hi [Fs | f0s], eight columns at a time: one read of Hi[i][k] serves them all
+    for (int c0 = 0; c0 < nx1; c0 += 8) {
+        double su[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (in) {
-#pragma unroll 4
-            for (int k = 0; k < n; ++k) su -= sHi[i * LDW + k] * sF[k * nx1 + c];
+#pragma unroll 2
+            for (int k = 0; k < n; ++k) {
+                const double hv = sHi[i * LDW + k];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) if (c0 + u < nx1) su[u] -= hv * sF[k * nx1 + c0 + u];
+            }
         }
-        if (in) Ku1[(size_t)i * nx1 + c] = su;
-        for (int r = i; r < NP; r += 64) {
-            FsT[c * NP + r] = r < n ? sF[r * nx1 + c] : 0.0;
-            if (r >= n) KuT[c * NP + r] = 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int c = c0 + u;
+            if (c >= nx1) break;
+            if (in) Ku1[(size_t)i * nx1 + c] = su[u];
+            for (int r = i; r < NP; r += 64) {
+                FsT[c * NP + r] = r < n ? sF[r * nx1 + c] : 0.0;
+                if (r >= n) KuT[c * NP + r] = 0.0;
+            }
+            if (in) KuT[c * NP + i] = su[u];
         }
-        if (in) KuT[c * NP + i] = su;
     }
 #ifdef FAC_PROF
     { long long tk = wall_clock64(); t_ku += tk - tk0; tk0 = tk; }
@@ -545,7 +567,7 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     // kernel is instruction bound): max_i |(Hs Hi v - v)_i| for v = ones and v = (+1,-1,...); it only decides
     // whether the solve refines with Hs itself
     double e = 0.0;
-    {
+    if (f.probe) {
         double v1 = 0.0, v2 = 0.0;
         if (in) {
 #pragma unroll 4
@@ -566,7 +588,7 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     for (int off = 32; off > 0; off >>= 1) e = fmax(e, __shfl_xor(e, off, 64));
     const bool anybad = __any(bad);
     if (i == 0) {
-        atomicMax(reinterpret_cast<unsigned long long*>(f.rho_dev + 3), (unsigned long long)__double_as_longlong(e));
+        if (f.probe) atomicMax(reinterpret_cast<unsigned long long*>(f.rho_dev + 3), (unsigned long long)__double_as_longlong(e));
         if (anybad) atomicOr(f.flag, 1);
         f.mflag[m] = anybad ? 1 : 0;
     }
@@ -620,8 +642,11 @@ int launch_factor(mpcqp_handle h, double rho, hipStream_t st) {
     return MPCQP_OK;
 }
 
-int launch_factor_batch(mpcqp_handle h, hipStream_t st) {
+// probe: estimate the accuracy of the explicit inverses (read back by a synchronous mpcqp_factor; a no_sync call has no use
+// for it -- the solve keeps the decision of the last synchronous one -- and it costs a sixth of the kernel)
+int launch_factor_batch(mpcqp_handle h, hipStream_t st, bool probe) {
     FacBatchParams f;
+    f.probe = probe ? 1 : 0;
     f.H = h->H; f.F = h->F; f.f0 = h->f0; f.umin = h->umin; f.umax = h->umax;
     f.d = h->d; f.Hs = h->Hs; f.Hi = h->Hi; f.W1 = h->W1; f.W2 = h->W2; f.Fs1 = h->Fs1; f.Ku1 = h->Ku1;
     f.FsT = h->FsT; f.KuT = h->KuT; f.lbs = h->lbs; f.ubs = h->ubs; f.rho_dev = h->rho_dev; f.flag = h->flag_dev;
