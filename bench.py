@@ -433,15 +433,21 @@ class LtvWorkload:
         fac_ms = timed(lambda: (lib.mpcqp_assemble(h, stream), lib.mpcqp_factor(h, C.byref(fo), stream)), 20) - asm_ms
         nx, nu, N = 4, 2, self.N
         n, p = N * nu, N * nx
-        # SURVEY.md 8(d) assembly flops per distinct system: rollout + Qbar Gamma (block lower triangular) + H as SYRK + F
-        flops = (2 * nx ** 3 * N + 2 * nx * nx * nu * (N - 1)) + 2 * nx * nx * nu * N * (N + 1) // 2 + p * n * (n + 1) \
+        # the dominant kernel of a step is the per-model factorisation (factor_wave_kernel: Jacobi scaling, blocked Cholesky,
+        # explicit inverse, affine maps).  Algorithmic flops per model: Cholesky n^3/3 + triangular inverse n^3/3 + Hi = T'T
+        # n^3/3 ... counted as multiply-add pairs x 2 = 2 n^3 in all, + the maps 2 n^2 (nx + 1)
+        flops = 2 * n ** 3 + 2 * n * n * (nx + 1)
+        tf = self.B * flops / (fac_ms * 1e-3) / 1e12
+        # SURVEY.md 8(d) assembly flops per distinct system, prediction-matrix form (rollout + Qbar Gamma + H as SYRK + F); the
+        # structured assembly that runs (assemble_wave_kernel) needs about a sixth of them and writes neither Gamma nor Qbar Gamma
+        asm_flops = (2 * nx ** 3 * N + 2 * nx * nx * nu * (N - 1)) + 2 * nx * nx * nu * N * (N + 1) // 2 + p * n * (n + 1) \
             + 2 * n * p * nx
-        tf = self.B * flops / (asm_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "kernel": "assemble_kernel (one workgroup per rollout's model)", "achieved": tf,
+        roofline = {"bound": "mfma", "kernel": "factor_wave_kernel (one wave per rollout's model)", "achieved": tf,
                     "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": None,
-                    "flops_per_launch": self.B * flops, "launch_ms": asm_ms,
-                    "note": "n = 40: tiles are too small for the MFMA peak; the kernel is bound by its own Gamma / Qbar Gamma "
-                            "traffic and the serial N-step chain (DESIGN.md section 4)"}
+                    "flops_per_launch": self.B * flops, "launch_ms": fac_ms,
+                    "assemble_TFLOPs_prediction_matrix_form": self.B * asm_flops / (asm_ms * 1e-3) / 1e12,
+                    "note": "n = 40 (padded to 48): 16 x 16 MFMA tiles inside dependent chains, 8 waves per SIMD in turn -- bound "
+                            "by instruction issue, far from the MFMA peak by construction (DESIGN.md section 4)"}
         config = {"workload": f"configs[3]: kinematic-bicycle LTV MPC closed loop nx=4 nu=2 N={N} (n={n}), "
                               f"{self.global_batch} parallel rollouts over {ranks.world} GPU(s), warm-start shifting, every "
                               "rollout re-linearised, assembled, factored and solved each step",
@@ -531,8 +537,10 @@ class RowsWorkload:
         k_mean, k_max = float(steps.mean().item()), int(steps.max().item())
         solve_ms = timed(lambda: pl.solve(self.x0), 10)
         # algorithmic bytes of the active-set kernel per instance: step s reads s+1 rows of the
-        # dual Hessian and reads + writes the m row residuals; the arg-max pass reads them once more
-        per_inst = float((8.0 * m * (steps * (steps + 1) / 2 + 4 * steps)).mean().item()) + 8.0 * (3 * n * n + 2 * m)
+        # dual Hessian and reads + writes the m row residuals (the scan for the next row rides on that pass; the first scan
+        # reads them once); the tail reads the k active rows of Cs (twice) and of CH.  No n x n matrix is read per instance
+        # since the tail certifies optimality from the set-up's |I - Ps Hi|
+        per_inst = float((8.0 * m * (steps * (steps + 1) / 2 + 3 * steps + 1) + 8.0 * 3 * n * steps).mean().item()) + 8.0 * 2 * m
         gbs = self.B * per_inst / (solve_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "rows_qp_kernel + its GEMM prologue (whole mpcqp_rows_solve_mpc call)",
                     "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
