@@ -655,7 +655,7 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st, bool probe) {
     const size_t lds = (size_t)4 * h->n * h->n * sizeof(double);
     f.use_lds = lds <= 128 * 1024;
     f.mflag = h->mflag;
-    hipError_t e = hipMemsetAsync(h->rho_dev, 0, 4 * sizeof(double), st);
+    hipError_t e = probe ? hipMemsetAsync(h->rho_dev, 0, 4 * sizeof(double), st) : hipSuccess;      // only the probe writes it
     if (e == hipSuccess) e = hipMemsetAsync(h->flag_dev, 0, sizeof(int), st);
     if (e == hipSuccess && f.use_lds)
         e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&factor_batch_kernel), lds);
