@@ -234,10 +234,10 @@ __device__ __forceinline__ void wave_sync() {
 //     P_k = Q_k + A_{k+1}' P_{k+1} A_{k+1}     (backwards from P_{N-1} = terminal weight)
 // the block (i, j), i <= j, is  B_i' Psi(j, i)' P_j B_j  (+ R on the diagonal): for every column j one chain
 //     V = P_j B_j;   for i = j .. 0:   H_ij = B_i' V,   V <- A_i' V.
-// Likewise F_i = B_i' S_i with S_k = Q_k Phi_k + A_{k+1}' S_{k+1} and f0_i = -B_i' s_i - R uref_i with
+// Likewise F_i = B_i' P_i Phi_i = V_i' Phi_i (forward, after the P_k) and f0_i = -B_i' s_i - R uref_i with
 // s_k = Q_k xref_k + A_{k+1}' s_{k+1}.  O(N^2) small products instead of the (N nx) x n x n contraction, and neither Gamma nor
 // Qbar Gamma is ever written: the 440 MB that kernel moved per step of BASELINE configs[3] (8,192 models) and 0.44 of the
-// 0.89 ms the step took.  One WAVE per model: the model, Phi_k and P_k live in LDS, lane (j, c) owns column j nu + c of H
+// 0.89 ms the step took.  One WAVE per model: the model and the V_k live in LDS, lane (j, c) owns column j nu + c of H
 // with its V column in registers.  Same quantities as assemble_kernel up to the order of summation.
 // Measured for 8,192 bicycle models (nx 4, nu 2, N 20): 0.14 ms against 0.44 ms.  It is bound by instruction issue, not by
 // memory or latency (~5,000 wave instructions per model, 16 of 64 lanes busy in the recursions, the triangle of chains half
@@ -261,10 +261,9 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
     double* sB = sA + nA * XX;                          // nA x (NX, nu)
     double* sQ = sB + nA * XU;                          // Q, terminal P
     double* sR = sQ + 2 * XX;                           // (nu, nu)
-    double* sPhi = sR + nu * nu;                        // N x (NX, NX): Phi_k = A_k ... A_0
-    double* sP = sPhi + N * XX;                         // N x (NX, NX): P_k
-    double* sS = sP + N * XX;                           // 2 x (NX, NX): S_k, ping-pong
-    double* sT = sS + 2 * XX;                           // (NX, NX): P_{k+1} A_{k+1}
+    double* sV = sR + nu * nu;                          // N x (NX, nu): V_k = P_k B_k
+    double* sP = sV + N * XU;                           // 2 x (NX, NX): P_k, ping-pong; later Phi_k, ping-pong
+    double* sT = sP + 2 * XX;                           // (NX, NX): P_{k+1} A_{k+1}
     double* ss = sT + XX;                               // 2 x NX: s_k, ping-pong
     double* sxr = ss + 2 * NX;                          // (N, NX), (N, nu): the model's references -- nothing inside the
     double* sur = sxr + N * NX;                         // backward chain may wait on global memory
@@ -278,48 +277,26 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
     for (int i = lane; i < nu * nu; i += 64) sR[i] = a.R[i];
     wave_sync();
     const int er = lane / NX, ec = lane % NX;           // lane < XX: element (er, ec) of the NX x NX recursions
-    // ---- forward: Phi_k ------------------------------------------------------------------------------------------------
-    for (int k = 0; k < N; ++k) {
-        const double* Ak = sA + (a.tv ? k * XX : 0);
-        if (lane < XX) {
-            double v;
-            if (k == 0) v = Ak[lane];
-            else {
-                v = 0.0;
-                const double* pk = sPhi + (k - 1) * XX;
-#pragma unroll
-                for (int b = 0; b < NX; ++b) v += Ak[er * NX + b] * pk[b * NX + ec];
-            }
-            sPhi[k * XX + lane] = v;
-            Phi[(size_t)(k * NX + er) * NX + ec] = v;
-        }
-        wave_sync();
-    }
-    // ---- backward: P_k, S_k, s_k; rows of F and f0 of stage k as soon as S_k, s_k exist ------------------------------------
+    // ---- backward: P_k, V_k = P_k B_k, s_k; rows of f0 of stage k as soon as s_k exists ---------------------------------------
     for (int k = N - 1; k >= 0; --k) {
         const double* Qk = (k == N - 1) ? sQ + XX : sQ;
         const double* A1 = sA + (a.tv ? (k + 1) * XX : 0);          // A_{k+1} (k < N-1 only)
-        double* Sk = sS + (k & 1) * XX; const double* S1 = sS + ((k + 1) & 1) * XX;
+        double* Pk = sP + (k & 1) * XX; const double* P1 = sP + ((k + 1) & 1) * XX;
         double* sk = ss + (k & 1) * NX; const double* s1 = ss + ((k + 1) & 1) * NX;
         if (k < N - 1 && lane < XX) {
             double t = 0.0;
-            const double* P1 = sP + (k + 1) * XX;
 #pragma unroll
             for (int b = 0; b < NX; ++b) t += P1[er * NX + b] * A1[b * NX + ec];
             sT[lane] = t;
         }
         wave_sync();
         if (lane < XX) {
-            double pv = Qk[lane], sv = 0.0;
-            const double* pk = sPhi + k * XX;
-#pragma unroll
-            for (int b = 0; b < NX; ++b) sv += Qk[er * NX + b] * pk[b * NX + ec];
+            double pv = Qk[lane];
             if (k < N - 1) {
 #pragma unroll
-                for (int b = 0; b < NX; ++b) { pv += A1[b * NX + er] * sT[b * NX + ec]; sv += A1[b * NX + er] * S1[b * NX + ec]; }
+                for (int b = 0; b < NX; ++b) pv += A1[b * NX + er] * sT[b * NX + ec];
             }
-            sP[k * XX + lane] = pv;
-            Sk[lane] = sv;
+            Pk[lane] = pv;
         }
         if (lane < NX) {
             double v = 0.0;
@@ -333,12 +310,12 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
         }
         wave_sync();
         const double* Bk = sB + (a.tv ? k * XU : 0);
-        for (int e = lane; e < nu * NX; e += 64) {                  // F rows of stage k: B_k' S_k
-            const int r = e / NX, c = e % NX;
+        for (int e = lane; e < XU; e += 64) {                       // V_k = P_k B_k  (NX, nu)
+            const int r = e / nu, c = e - r * nu;
             double v = 0.0;
 #pragma unroll
-            for (int b = 0; b < NX; ++b) v += Bk[b * nu + r] * Sk[b * NX + c];
-            F[(size_t)(k * nu + r) * NX + c] = v;
+            for (int b = 0; b < NX; ++b) v += Pk[r * NX + b] * Bk[b * nu + c];
+            sV[k * XU + e] = v;
         }
         for (int r = lane; r < nu; r += 64) {                       // f0 rows of stage k
             double v = 0.0;
@@ -349,21 +326,40 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
         }
     }
     wave_sync();
+    // ---- forward: Phi_k, and with it the rows of F of stage k: S_k = sum_{l >= k} Psi(l,k)' Q_l Phi_l = P_k Phi_k because
+    // Phi_l = Psi(l,k) Phi_k, so F_k = B_k' S_k = V_k' Phi_k -- no second recursion and no Phi_k kept ------------------------------
+    double* sPhi = sP;
+    for (int k = 0; k < N; ++k) {
+        const double* Ak = sA + (a.tv ? k * XX : 0);
+        double* pk = sPhi + (k & 1) * XX; const double* p1 = sPhi + ((k + 1) & 1) * XX;
+        if (lane < XX) {
+            double v;
+            if (k == 0) v = Ak[lane];
+            else {
+                v = 0.0;
+#pragma unroll
+                for (int b = 0; b < NX; ++b) v += Ak[er * NX + b] * p1[b * NX + ec];
+            }
+            pk[lane] = v;
+            Phi[(size_t)(k * NX + er) * NX + ec] = v;
+        }
+        wave_sync();
+        const double* Vk = sV + k * XU;
+        for (int e = lane; e < nu * NX; e += 64) {                  // F rows of stage k: V_k' Phi_k
+            const int r = e / NX, c = e % NX;
+            double v = 0.0;
+#pragma unroll
+            for (int b = 0; b < NX; ++b) v += Vk[b * nu + r] * pk[b * NX + c];
+            F[(size_t)(k * nu + r) * NX + c] = v;
+        }
+    }
+    wave_sync();
     // ---- columns of H -----------------------------------------------------------------------------------------------------
     for (int col = lane; col < n; col += 64) {
         const int j = col / nu, c = col - j * nu;
         double v[NX];
-        {
-            const double* Pj = sP + j * XX;
-            const double* Bj = sB + (a.tv ? j * XU : 0);
 #pragma unroll
-            for (int r = 0; r < NX; ++r) {
-                double t = 0.0;
-#pragma unroll
-                for (int b = 0; b < NX; ++b) t += Pj[r * NX + b] * Bj[b * nu + c];
-                v[r] = t;
-            }
-        }
+        for (int r = 0; r < NX; ++r) v[r] = sV[j * XU + r * nu + c];
         for (int i = j; i >= 0; --i) {
             const double* Bi = sB + (a.tv ? i * XU : 0);
             const double* Ai = sA + (a.tv ? i * XX : 0);
@@ -411,7 +407,7 @@ static int launch_assemble_wave(mpcqp_handle h, hipStream_t st) {
     const int nx = h->dims.nx, nu = h->dims.nu, N = h->dims.N;
     if (h->dims.n_models < 2 || nx > 8) return -1;
     const int nA = h->dims.time_varying ? N : 1, XX = nx * nx;
-    const size_t lds = ((size_t)nA * (XX + nx * nu) + 2 * XX + nu * nu + 2 * (size_t)N * XX + 3 * XX + 2 * nx +
+    const size_t lds = ((size_t)nA * (XX + nx * nu) + 2 * XX + nu * nu + (size_t)N * nx * nu + 3 * XX + 2 * nx +
                         (size_t)N * (nx + nu)) * sizeof(double);
     if (lds > 40 * 1024) return -1;
     AsmParams a;
