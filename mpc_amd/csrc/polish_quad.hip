@@ -930,6 +930,7 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 // an ADMM iterate the number of bounds the unconstrained minimiser violates predicts the number of active-set steps:
 // instances are bucketed by that count (32 buckets, largest first) and the first pass reads them through the queue.
 constexpr int NBIN = 32;
+constexpr int SMALL_BATCH = 8192;
 
 // xu = Ku1 [x0; 1] for 16 instances per wave on fp64 MFMA tiles (A = 16 rows of Ku1, B = [x0; 1] of 16 instances), the
 // violated rows counted straight from the D registers: lane l holds rows (l>>4)+4r of instance l&15
@@ -1070,6 +1071,18 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
         a.qin = order; a.qin_count = count;
     }
     if (stop_after == 2) return 0;
+    // A small cold batch (a 1/8 shard of the headline batch and below) lasts as long as its slowest instance, whatever the
+    // launch holds: ONE pass with 16 lanes per instance and 32 slots takes it all the way (32 instances per workgroup: 8,192
+    // instances are one workgroup per CU; shorter steps than 8 lanes, and ~no instance outgrows 32 rows), its rare overflow
+    // goes straight to the 64-row pass with the state record that pass B would have written.  Two launches fewer, and no
+    // second staging + latency chain behind the first (8,192 instances: 155 -> see DESIGN.md section 7).
+    if (p.cold && p.B <= SMALL_BATCH && p.hand_buf2 && stop_after != 2) {
+        PolParams s16 = p;
+        s16.qin = nullptr; s16.qin_count = nullptr; s16.qout = q2; s16.qout_count = counters + 1;
+        s16.hand_in = nullptr; s16.hand_out = p.hand_buf2; s16.hand_out_cap = p.hand_cap2; s16.hand_zw = 0;
+        const int rc16 = launch_oct_rp<16, 32, 512>(s16, p.B, st);
+        if (rc16 >= 0) return rc16;
+    }
     // fewer blocks of 64 instances than the device has CUs (a 1/8 shard of the headline batch): half-size workgroups, so that
     // the launch covers twice as many CUs with one wave per SIMD -- the latency of the heaviest block is what such a launch lasts
     int rc = p.B < 64 * 256 ? launch_oct_rp<8, 16, 256>(a, p.B, st) : launch_oct_rp<8, 16, 512>(a, p.B, st);
