@@ -567,7 +567,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     int* q1 = h->it_ws + 3 * (size_t)h->Bcap;
     int* q2 = q1 + h->Bcap;
     int* counters = q2 + h->Bcap;
-    // small active sets (the usual case): eight lanes per instance with Hs^-1 in LDS, two passes (polish_quad.hip);
+    // small active sets (the usual case): a few lanes per instance with Hs^-1 in LDS, a cascade of passes (polish_quad.hip);
     // what those cannot finish is queued in q2 for the wave-per-instance kernel.  Shapes the fast path does not
     // take (refinement requested, polish off, n > 128) run the wave-per-instance kernel on the whole batch.
     // diagnostics for bench.py: stages bit 2 stops after the first pass, bit 3 after the cold-start ordering kernels

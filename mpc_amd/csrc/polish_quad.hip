@@ -6,7 +6,10 @@
 // per-instance arithmetic is a few thousand flops and a one-wave-per-instance kernel would spend its time issuing 64-wide
 // instructions for 7-element vectors and walking Cholesky columns one by one.
 //
-// Mapping: G = 8 (first pass) or 32 (second pass) lanes per instance, 512-thread workgroups.
+// Mapping: G lanes per instance, 512-thread workgroups; the cascade is G = 8 / 16 slots (every instance) -> G = 32 or 16 /
+// 32 slots (what outgrew the first; 16 lanes when that queue is long) -> G = 64 / 64 slots -> polish.hip's any-size kernel,
+// each pass handing its whole working state to the next.  A cold batch of 8,192 instances or fewer is ONE pass with
+// G = 16 / 32 slots (launch_polish_quad).
 //   * Hi (n x n, odd row stride) is staged ONCE per workgroup into LDS and serves all its instances;
 //     it is symmetric, so "column p restricted to my rows" is a contiguous row read.
 //   * lane g of the group owns the row pairs (2 G j + 2 g, + 1), j < RP, of x in registers.
