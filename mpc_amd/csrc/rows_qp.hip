@@ -117,6 +117,87 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams g) {
             }
 }
 
+// The same product when C is small and K long (Xu = -Qs Hi: 256 x 600 over K = 600 is 40 of the tiles above, each walking
+// all of K): 32 x 32 per workgroup and the FOUR WAVES SPLIT K, each accumulating the whole tile over its quarter; the
+// partial tiles meet in LDS in a fixed order (deterministic), wave w finishes rows 8w .. 8w+7.  Four times the workgroups and
+// a quarter of the chain.
+__global__ __launch_bounds__(256) void gemm_nt_splitk_kernel(GemmParams g) {
+    __shared__ double part[4][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int kblocks = (g.K + 15) / 16, per = (kblocks + 3) / 4;
+    const int kbeg = wave * per * 16, kend = min(g.K, (wave + 1) * per * 16);
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0, 0, 0, 0};
+    const double* ar[2]; const double* br[2];
+    bool av[2], bv[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int i = i0 + 16 * t + col, j = j0 + 16 * t + col;
+        av[t] = i < g.M; bv[t] = j < g.N;
+        ar[t] = g.A + (size_t)min(i, g.M - 1) * g.lda;
+        br[t] = g.B + (size_t)min(j, g.N - 1) * g.ldb;
+    }
+    for (int k0 = kbeg; k0 < kend; k0 += 16) {
+        double a[2][4], b[2][4];
+        const int kb = k0 + 4 * kq;
+        if (g.vec && k0 + 16 <= g.K) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const double2 a0 = *reinterpret_cast<const double2*>(ar[t] + kb), a1 = *reinterpret_cast<const double2*>(ar[t] + kb + 2);
+                const double2 b0 = *reinterpret_cast<const double2*>(br[t] + kb), b1 = *reinterpret_cast<const double2*>(br[t] + kb + 2);
+                a[t][0] = a0.x; a[t][1] = a0.y; a[t][2] = a1.x; a[t][3] = a1.y;
+                b[t][0] = b0.x; b[t][1] = b0.y; b[t][2] = b1.x; b[t][3] = b1.y;
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = kb + e;
+                    a[t][e] = k < g.K ? ar[t][k] : 0.0;
+                    b[t][e] = k < g.K ? br[t][k] : 0.0;
+                }
+        }
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (!av[t]) a[t][e] = 0.0;
+                if (!bv[t]) b[t][e] = 0.0;
+            }
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                for (int tj = 0; tj < 2; ++tj) acc[ti][tj] = mfma_f64(a[ti][e], b[tj][e], acc[ti][tj]);
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) part[wave][16 * ti + kq + 4 * r4][16 * tj + col] = acc[ti][tj][r4];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {
+        const int r = e >> 5, c = e & 31;
+        const int i = i0 + r, j = j0 + c;
+        if (i < g.M && j < g.N) {
+            double* cp = g.C + (size_t)i * g.ldc + j;
+            double v = g.alpha * (((part[0][r][c] + part[1][r][c]) + part[2][r][c]) + part[3][r][c]);
+            if (g.bias) v += g.bias[j];
+            if (g.cscale) v = g.cdiv ? v / g.cscale[j] : v * g.cscale[j];
+            if (g.beta != 0.0) v += g.beta * (g.Cin ? g.Cin[(size_t)i * g.ldc + j] : *cp);
+            *cp = v;
+        }
+    }
+}
+
 int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int M, int N, int K,
                    double alpha, double beta, hipStream_t st, const double* bias = nullptr, const double* cscale = nullptr,
                    int cdiv = 0, const double* Cin = nullptr) {
@@ -124,7 +205,10 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
     g.bias = bias; g.cscale = cscale; g.cdiv = cdiv; g.Cin = Cin;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
     g.vec = (lda % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0);
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
+    if ((long)ceil_div(N, 64) * ceil_div(M, 64) < 128 && K >= 256)      // few tiles, long K: split K over the waves
+        hipLaunchKernelGGL(gemm_nt_splitk_kernel, dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, st, g);
+    else
+        hipLaunchKernelGGL(gemm_nt_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
 }
 
