@@ -173,7 +173,10 @@ int mpcqp_recenter(mpcqp_handle h, void* stream);
  *        12 diagnostics of the last solve (96 values): [0] instances handed to the second active-set pass (routed by the
  *           cold-start ordering + overflow of the first), [1] handed on to the 64-row pass, [2] instances the first pass
  *           took, [3] handed to the any-size pass, [16..48) histogram of the cold-start keys
- *        13 G (m,n)  14 E (m,nx)  15 h0 (m): the condensed rows of the general-constraint mode                       */
+ *        13 G (m,n)  14 E (m,nx)  15 h0 (m): the condensed rows of the general-constraint mode
+ * Gamma: with one model per instance and nx <= 8 the assembly does not form the prediction matrices (H, F, f0 come from the
+ * backward recursion of the dynamics); selector 3 then runs the prediction-matrix assembly first, on `stream`.
+ * Diagnostics [12]: a cold batch of 8,192 instances or fewer is one 32-slot pass, so [0] and [2] stay 0 for it. */
 int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, void* stream);
 
 /* -- dense QP: the reference's literal call  cvxopt.solvers.qp(P, q, G, h[, A, b]) ---------------------
