@@ -165,10 +165,21 @@ class Ranks:
             self.dist = dist
         self.cdev = self.dev if self.backend in (None, "nccl") else torch.device("cpu")
         self._bar = torch.zeros(1, dtype=torch.int32, device=self.cdev)
-        self._flags = [torch.zeros(1, dtype=torch.int32, device=self.cdev) for _ in range(8)]
-        self._pending = [None] * 8
+        # the worst status of every step goes into one of two banks of 8 ints; a full bank travels in ONE all-reduce
+        self._banks = [torch.zeros(8, dtype=torch.int32, device=self.cdev) for _ in range(2)]
+        self._pending = [None, None]
         self._n = 0
+        self._failed = None         # running MAX over the reduced banks (a tensor on cdev)
         self.all_ok = True
+        if self.dist is not None:
+            # first use of a collective on these buffers and of the two tiny torch kernels of _check loads code objects
+            # (tens of milliseconds on ROCm): not inside the timed region
+            for bank in (0, 1):
+                self.dist.all_reduce(self._banks[bank], op=self.dist.ReduceOp.MAX)
+                self._check(bank)
+            self._failed = None
+            if self.cdev.type == "cuda":
+                torch.cuda.synchronize(self.dev)
 
     def barrier(self):
         # an all-reduce of one int synchronises the ranks on every backend (torch's gloo barrier() hung on the rehearsal
@@ -179,35 +190,49 @@ class Ranks:
                 self.torch.cuda.synchronize(self.dev)
 
     def flag_allreduce(self, status_dev):
-        """all-reduce(MAX) of this step's worst per-instance status (0 = every instance of every rank solved: the
-        convergence flag).  The reduce of step i is in flight while the next steps compute: a ring of 8 flag buffers, and a
-        buffer is only written again once the collective that read it has finished (by then it long has: waiting for the
-        reduce of the step just before would stall the compute stream behind a collective that cannot get a CU while the
-        solve kernels fill the device).  drain() ends the timed region, so every collective is inside it."""
+        """all-reduce(MAX) of every step's worst per-instance status (0 = every instance of every rank solved: the
+        convergence flag).  Bucketed: the flags of 8 consecutive steps are reduced by one collective (measured with one
+        rank on RCCL, tools/collective_cost.py: an asynchronous all-reduce per step costs the compute stream 23 us whatever
+        its size -- a fifth of an 8,192-instance step -- the reduction kernel that writes the flag 5-14 us).  Two banks: a
+        bank is only written again once the collective that read it has finished (16 steps later it long has).  drain()
+        ends the timed region, so every collective is inside it."""
         if self.dist is None:
             return
-        j = self._n & 7
-        self._n += 1
-        if self._pending[j] is not None:
-            self._pending[j].wait()
-        f = self._flags[j]
+        bank, j = (self._n >> 3) & 1, self._n & 7
+        if j == 0 and self._pending[bank] is not None:
+            self._pending[bank].wait()
+            self._check(bank)
+            self._pending[bank] = None
+        f = self._banks[bank][j:j + 1]
         if self.cdev.type == "cuda":
             # RCCL: the reduction kernel writes the flag buffer itself, on the compute stream, which the collective's stream waits for
             self.torch.amax(status_dev, dim=0, keepdim=True, out=f)
         else:
             # gloo: a BLOCKING copy to the host tensor -- it must have landed before the collective reads it
             f.copy_(self.torch.amax(status_dev, dim=0, keepdim=True))
-        self._pending[j] = self.dist.all_reduce(f, op=self.dist.ReduceOp.MAX, async_op=True)
+        self._n += 1
+        if j == 7:
+            self._pending[bank] = self.dist.all_reduce(self._banks[bank], op=self.dist.ReduceOp.MAX, async_op=True)
+
+    def _check(self, bank):
+        # a reduced bank: any non-zero entry is a step in which some instance of some rank was not solved
+        bad = self._banks[bank].amax()
+        self._failed = bad if self._failed is None else self.torch.maximum(self._failed, bad)
 
     def drain(self):
-        for j, w in enumerate(self._pending):
+        if self.dist is None or not self._n:
+            return
+        if self._n & 7:         # the partly filled bank (its other entries are zero or already-reduced values)
+            bank = (self._n >> 3) & 1
+            self._pending[bank] = self.dist.all_reduce(self._banks[bank], op=self.dist.ReduceOp.MAX, async_op=True)
+        for bank, w in enumerate(self._pending):
             if w is not None:
                 w.wait()
-                self._pending[j] = None
-        if self.dist is not None and self._n:
-            if self.cdev.type == "cuda":
-                self.torch.cuda.synchronize(self.dev)
-            self.all_ok = self.all_ok and all(int(f.item()) == 0 for f in self._flags[:min(self._n, 8)])
+                self._check(bank)
+                self._pending[bank] = None
+        if self.cdev.type == "cuda":
+            self.torch.cuda.synchronize(self.dev)
+        self.all_ok = self.all_ok and (self._failed is None or int(self._failed.item()) == 0)
 
     def max_over_ranks(self, seconds):
         if self.dist is None:
@@ -364,7 +389,7 @@ class BoxWorkload:
                   "p50_batch_latency_ms": p50_ms, "p99_batch_latency_ms": p99_ms, "mean_batch_latency_ms": both_ms,
                   "admm_kernel_ms": admm_ms, "polish_kernels_ms": max(both_ms - admm_ms, 0.0),
                   "first_pass_ms": pass_a_ms, "cold_order_ms": order_ms,
-                  "collectives_in_step": "all_reduce(MAX) of the worst status (0 = all solved)" if ranks.world > 1 else "none",
+                  "collectives_in_step": "all_reduce(MAX) of the worst status of every step (0 = all solved), 8 steps per collective" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend, "allgather_ms": allgather_ms, "shard_sweep_ms": sweep,
                   "hbm_GBps_compulsory": B * (8 * prob["nx"] + 8 * n + 16 + 4 * 8 * n) / (both_ms * 1e-3) / 1e9}
         return config, roofline
@@ -456,7 +481,7 @@ class LtvWorkload:
                   "ms_per_closed_loop_step": dt / args.steps * 1e3, "assemble_ms": asm_ms, "factor_ms": fac_ms,
                   "active_set_steps_mean_last": st_mean, "solved_fraction_last": solved,
                   "final_abs_y_max": float(self.x[:, 1].abs().max().item()),
-                  "collectives_in_step": "all_reduce(MAX) of the worst status (0 = all solved)" if ranks.world > 1 else "none",
+                  "collectives_in_step": "all_reduce(MAX) of the worst status of every step (0 = all solved), 8 steps per collective" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend}
         return config, roofline
 
@@ -552,7 +577,7 @@ class RowsWorkload:
                   "parallelism": f"dp{ranks.world} (independent shards)", "setup_ms": self.setup_ms,
                   "active_set_steps_mean": k_mean, "active_set_steps_max": k_max,
                   "solved_fraction": float((info.status == 0).float().mean().item()), "batch_latency_ms": solve_ms,
-                  "collectives_in_step": "all_reduce(MAX) of the worst status (0 = all solved)" if ranks.world > 1 else "none",
+                  "collectives_in_step": "all_reduce(MAX) of the worst status of every step (0 = all solved), 8 steps per collective" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend}
         return config, roofline
 
@@ -616,6 +641,8 @@ def run_rank(args):
                "n_gpus": ranks.world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
                "config": config, "roofline": roofline}
+        if ranks.dist is not None:
+            out["config"]["all_ranks_all_solved_every_step"] = bool(ranks.all_ok)      # what the flag collectives returned
         if ranks.world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = wl.cpu_baseline()
