@@ -150,18 +150,21 @@ class Ranks:
         self.backend = None
         ndev = max(1, torch.cuda.device_count())
         self.local = local % ndev
-        torch.cuda.set_device(self.local)
-        self.dev = torch.device(f"cuda:{self.local}")
+        self.has_gpu = torch.cuda.device_count() > 0        # False only in the CPU tests of this class (gloo, host tensors)
+        if self.has_gpu:
+            torch.cuda.set_device(self.local)
+        self.dev = torch.device(f"cuda:{self.local}" if self.has_gpu else "cpu")
         # MPC_BENCH_FORCE_DIST=1: initialise the process group even for one rank (exercises the RCCL calls on a one-GPU box)
         if self.world > 1 or (os.environ.get("MPC_BENCH_FORCE_DIST") and "RANK" in os.environ):
             import torch.distributed as dist
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
             self.backend = os.environ.get("MPC_BENCH_BACKEND", "nccl")
-            if self.backend == "nccl":
-                dist.init_process_group("nccl", device_id=self.dev)
-            else:
-                dist.init_process_group(self.backend)
+            if not dist.is_initialized():
+                if self.backend == "nccl":
+                    dist.init_process_group("nccl", device_id=self.dev)
+                else:
+                    dist.init_process_group(self.backend)
             self.dist = dist
         self.cdev = self.dev if self.backend in (None, "nccl") else torch.device("cpu")
         self._bar = torch.zeros(1, dtype=torch.int32, device=self.cdev)

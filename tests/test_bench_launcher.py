@@ -66,3 +66,51 @@ def test_launcher_starts_fresh_ranks_and_relays_rank0(tmp_path):
         assert len(line) == 1
         out = json.loads(line[0])
         assert out["n_gpus"] == 2 and out["sum"] == 3 and out["argv"][:2] == ["--steps", "1"]
+
+
+def _ranks_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), MPC_BENCH_BACKEND="gloo")
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+    import bench
+    r = bench.Ranks()
+    try:
+        ok = r.world == world and r.backend == "gloo" and r.cdev.type == "cpu"
+        # 21 steps, every instance solved on every rank: the flags of 8 steps travel in one collective, the last 5 in drain()
+        for _ in range(21):
+            r.flag_allreduce(torch.zeros(64, dtype=torch.int32))
+        r.drain()
+        ok = ok and r.all_ok is True
+        # one instance of rank 1 unsolved in step 13 of the next 19: every rank learns it
+        for it in range(19):
+            st = torch.zeros(64, dtype=torch.int32)
+            if rank == 1 and it == 13:
+                st[5] = 2
+            r.flag_allreduce(st)
+        r.drain()
+        ok = ok and r.all_ok is False
+        r.barrier()
+        ok = ok and r.max_over_ranks(1.0 + rank) == float(world)
+        q.put((rank, bool(ok)))
+    finally:
+        r.finish()
+
+
+def test_ranks_bucketed_status_flags_two_ranks_gloo():
+    """bench.py's Ranks (the N > 1 path: barrier, bucketed status all-reduce, max over ranks) with two gloo ranks on
+    the CPU: what one rank fails to solve in one step reaches every rank, also from a partly filled bank."""
+    import socket
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_ranks_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert res == {0: True, 1: True}
