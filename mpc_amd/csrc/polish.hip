@@ -428,6 +428,27 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
                 wave_sync();
             }
             status = MPCQP_SOLVED;
+            if (p.refine > 0) {
+                // The refinement moves the free rows with Hs itself; nothing has checked the moved point yet.  When the
+                // explicit inverse is as poor as a condition number of 1e13 makes it, the corrected rows can leave the box
+                // or the corrected multipliers change sign: such an answer is not SOLVED.  Overshoots at rounding level are
+                // clipped, so that U is always inside the bounds.
+                bool off = false;
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int j = lane + 64 * q;
+                    if (j < n) {
+                        if (side[q] == 0) {
+                            const double tol = 1e-9 * fmax(1.0, fmax(fabs(hi[q]), fabs(lo[q])));
+                            off = off || x[q] > hi[q] + tol || x[q] < lo[q] - tol;
+                            x[q] = fmin(fmax(x[q], lo[q]), hi[q]);
+                        } else {
+                            off = off || lam[q] * side[q] < -1e-9 * fmax(1.0, fabs(qs[q]));
+                        }
+                    }
+                }
+                if (__any(off)) status = MPCQP_SOLVED_INACCURATE;
+            }
         }
     }
 
