@@ -3,6 +3,13 @@
 #pragma once
 #include "common.h"
 
+// magnitude of a row's FINITE bounds (>= 1): what its tolerances scale with.  An infinite side (u_min = -inf: the row is
+// bounded on one side only) must not turn the tolerance of the finite side into infinity
+__device__ __forceinline__ double bound_scale(double lo, double hi) {
+    const double a = isfinite(hi) ? fabs(hi) : 0.0, b = isfinite(lo) ? fabs(lo) : 0.0;
+    return fmax(1.0, fmax(a, b));
+}
+
 struct PolParams {
     const double *Hs, *Hi, *FsT, *KuT, *lbs, *ubs, *d;     // FsT, KuT: (nx+1, NP)
     const double* x0;

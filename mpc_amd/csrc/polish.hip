@@ -207,7 +207,7 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
             lam[q] = p.rho * ww;
             // (z, w) are recovered from the kernel's (v, c) state, so "at the bound" and "w != 0"
             // hold up to rounding only
-            const double tz = 1e-9 * fmax(1.0, fmax(fabs(hi[q]), fabs(lo[q])));
+            const double tz = 1e-9 * bound_scale(lo[q], hi[q]);
             const double tw = 1e-12 * fmax(1.0, fabs(zz));
             side[q] = (zz >= hi[q] - tz && ww > tw) ? 1 : ((zz <= lo[q] + tz && ww < -tw) ? -1 : 0);
         }
@@ -276,7 +276,7 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
                 const int j = lane + 64 * q;
                 vb[q] = -1.0;
                 if (j < n && side[q] == 0) {
-                    const double tol = 1e-12 * fmax(1.0, fmax(fabs(hi[q]), fabs(lo[q])));
+                    const double tol = 1e-12 * bound_scale(lo[q], hi[q]);
                     const double v = fmax(x[q] - hi[q], lo[q] - x[q]);
                     if (v > tol) vb[q] = v;
                 }
@@ -439,7 +439,7 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
                     const int j = lane + 64 * q;
                     if (j < n) {
                         if (side[q] == 0) {
-                            const double tol = 1e-9 * fmax(1.0, fmax(fabs(hi[q]), fabs(lo[q])));
+                            const double tol = 1e-9 * bound_scale(lo[q], hi[q]);
                             off = off || x[q] > hi[q] + tol || x[q] < lo[q] - tol;
                             x[q] = fmin(fmax(x[q], lo[q]), hi[q]);
                         } else {

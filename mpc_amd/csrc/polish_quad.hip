@@ -234,7 +234,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         for (int j = 0; j < RPL; ++j) {
             const int row = ROWJ(j);
             const double hi = sUb[row], lo = sLb[row];
-            const double tz = 1e-9 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
+            const double tz = 1e-9 * bound_scale(lo, hi);
             const double tw = 1e-12 * fmax(1.0, fabs(zz[j]));
             if (row < n) {
                 // cold (no ADMM iterate): start from the empty set.  Guessing the bounds the unconstrained minimiser
@@ -581,7 +581,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         PROF_MARK(9);
         if (code >= 0) {                    // the violation itself: add the row's tolerance back
             const double hi = sUb[code >> 1], lo = sLb[code >> 1];
-            best += 1e-12 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
+            best += 1e-12 * bound_scale(lo, hi);
         }
         if (!__any(has)) break;
         if (has && ++guard > p.max_steps) { fail = true; why = 5; run = false; has = false; }
@@ -855,7 +855,7 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
         sUb[j] = (j < n) ? p.ubs[j] : 1e300;
         sD[j] = (j < n) ? p.d[j] : 0.0;
         const double lo = (j < n) ? p.lbs[j] : -1e300, hi = (j < n) ? p.ubs[j] : 1e300;
-        const double tol = 1e-12 * fmax(1.0, fmax(fabs(hi), fabs(lo)));
+        const double tol = 1e-12 * bound_scale(lo, hi);
         sBT[j] = make_double2(lo - tol, hi + tol);
     }
     {   // the map [Ku | ku]': (nx+1) rows of NQ, 16-byte loads

@@ -418,3 +418,34 @@ def test_hopelessly_conditioned_model_is_never_reported_solved_when_it_is_not():
     assert bool((lam[at_ub & ~at_lb] >= -1e-6 * lam.abs().max()).all())
     assert bool((lam[at_lb & ~at_ub] <= 1e-6 * lam.abs().max()).all())
     assert int((st == 0).sum()) > batch // 2
+
+
+@pytest.mark.parametrize("batch,max_iter", [(65, 0), (9000, 0), (65, 5)])
+def test_one_sided_input_bounds_match_oracle(batch, max_iter):
+    """u_min = -inf on one input and u_max = +inf on another: rows bounded on one side only.  (Found by tools/fuzz_edges.py:
+    the violation tolerance of a row was scaled with max(|lo|, |hi|), so an infinite side made the finite one untestable and
+    the bound was silently ignored.)"""
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_box_qp
+    rng = np.random.default_rng(8)
+    nx, nu, N = 6, 3, 12
+    A = 0.9 * np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    B = rng.standard_normal((nx, nu)) / np.sqrt(nx) + 0.1
+    Q = np.eye(nx); R = 0.1 * np.eye(nu)
+    umin = np.array([-np.inf, -0.3, -0.2]); umax = np.array([0.4, 0.25, np.inf])
+    x0 = rng.uniform(-2, 2, (batch, nx))
+    pl = Planner(nx, nu, N).set_model(A, B).set_cost(Q, R, 2 * Q).set_constraints(umin, umax)
+    U = pl.solve(x0, max_iter=max_iter).cpu().numpy().reshape(batch, -1)
+    assert (pl.info.status.cpu().numpy() == 0).all()
+    obj = pl.info.obj.cpu().numpy()
+    H, F, f0 = mo.condense(dict(N=N, nx=nx, nu=nu, A=A, B=B, Q=Q, R=R, P=2 * Q))
+    lb, ub = np.tile(umin, N), np.tile(umax, N)
+    assert (U <= ub + 1e-12).all() and (U >= lb - 1e-12).all()
+    nbind = 0
+    for i in range(0, batch, max(1, batch // 12)):
+        s = solve_box_qp(H, F @ x0[i] + f0, lb, ub)
+        assert np.abs(U[i] - s["x"]).max() <= PRIMAL_RTOL * max(1.0, np.abs(s["x"]).max()), i
+        assert abs(obj[i] - s["primal objective"]) <= OBJ_RTOL * max(abs(s["primal objective"]), 1e-12), i
+        nbind += int((np.abs(s["x"] - ub) < 1e-9).sum() + (np.abs(s["x"] - lb) < 1e-9).sum())
+    assert nbind > 0
