@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void scale_cols_kernel(ScaleParams p) {
         if (tid < s) red[tid] = fmax(red[tid], red[tid + s]);
         __syncthreads();
     }
-    if (tid == 0) *p.sigma = p.sigma_rel * fmax(red[0], 1e-300);
+    if (tid == 0) *p.sigma = p.sigma_rel * (red[0] > 0.0 ? red[0] : 1.0);
 }
 
 __global__ __launch_bounds__(256) void scale_hessian_kernel(ScaleParams p) {

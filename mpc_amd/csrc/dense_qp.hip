@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void dense_qp_kernel(DenseParams p) {
         w.Cs[idx] = src[j] * w.d[j] / w.rn[r];
     }
     for (int r = tid; r < mc; r += 256) w.cs[r] = (r < pe ? b[r] : h[r - pe]) / w.rn[r];
-    sigma = p.sigma_rel * fmax(dmax, 1e-300);
+    sigma = p.sigma_rel * (dmax > 0.0 ? dmax : 1.0);     // P = 0 (an LP): the scaled rows set the unit
     for (int idx = tid; idx < n * n; idx += 256) w.W[idx] = w.Ps[idx] + ((idx / n == idx % n) ? sigma : 0.0);
     __syncthreads();
     if (wg_chol(w.W, n, n, &sflag) >= 0) status = 3;     // P is not positive semidefinite

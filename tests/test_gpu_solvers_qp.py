@@ -86,6 +86,35 @@ def test_status_and_errors():
     solvers.options["show_progress"] = False
 
 
+def test_degenerate_shapes_and_scales():
+    """No rows, one variable, equalities only, duplicated rows, a rank-one and a zero Hessian inside a box, and problem
+    data scaled by 1e+-8: every one the interior-point reference accepts (rank([P; A; G]) = n)."""
+    from mpc_amd import solvers
+    from oracle.qp_oracle import solve_qp
+    rng = np.random.default_rng(3)
+    n = 6
+    M = rng.standard_normal((n, n)); P = M @ M.T + 0.1 * np.eye(n); q = rng.standard_normal(n)
+    A = rng.standard_normal((2, n)); b = rng.standard_normal(2)
+    G = rng.standard_normal((9, n)); h = np.abs(rng.standard_normal(9)) + 0.1
+    box, one = np.vstack([np.eye(n), -np.eye(n)]), np.ones(2 * n)
+    P1 = np.zeros((n, n)); P1[0, 0] = 1.0
+    cases = [(P, q, None, None, None, None), (np.array([[2.0]]), np.array([1.0]), np.array([[1.0]]), np.array([-3.0]), None, None),
+             (P, q, None, None, A, b), (P, q, np.vstack([G, G]), np.concatenate([h, h]), None, None),
+             (P, q, None, None, np.vstack([A, A]), np.concatenate([b, b])), (P1, q, box, one, None, None),
+             (np.zeros((n, n)), q, box, one, None, None), (1e8 * P, 1e8 * q, 1e-4 * G, 1e-4 * h, None, None),
+             (1e-8 * P, 1e-8 * q, G, h, None, None)]
+    for P_, q_, G_, h_, A_, b_ in cases:
+        s = solve_qp(P_, q_, G_, h_, A_, b_)
+        assert s["status"] == "optimal"
+        col = lambda v: None if v is None else v.reshape(-1, 1)
+        sol = solvers.qp(P_, col(q_), G_, col(h_), A_, col(b_))
+        assert sol["status"] == "optimal"
+        x = np.array(sol["x"]).ravel()
+        assert np.abs(x - s["x"]).max() <= 1e-6 * max(np.abs(s["x"]).max(), 1.0)
+        assert abs(sol["primal objective"] - s["primal objective"]) <= 1e-8 * max(abs(s["primal objective"]), 1e-9)
+    assert solvers.qp(P1, q.reshape(-1, 1))["status"] == "unknown"           # unbounded below: a status, not an exception
+
+
 def test_batched_dense_and_cost_builder():
     import torch
     from mpc_amd.helper_funcs import getQuadProgCostFunction
