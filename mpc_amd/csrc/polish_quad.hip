@@ -134,10 +134,13 @@ __device__ __forceinline__ double frcp(double x) {
 
 // row of the lane's j-th register element: pairs (16 jj + 2 g, +1) -- two adjacent rows per lane so that LDS
 // reads pair up (ds_read2_b64) and global loads/stores are 16 bytes per lane, 128 bytes per instance
-#define ROWJ(j) (2 * G * ((j) >> 1) + ((j) & 1) + 2 * g)
-#define COLJ(j) (2 * G * ((j) >> 1) + ((j) & 1))
+// With 8 lanes per instance a 16-byte LDS read of one row pair per lane covers 128 bytes per instance, and the hardware
+// serves such a read 16 lanes at a time: {0-3, 12-15, 20-27} = the same halves of instances 0/3 and of 1/2.  Every row of Hi
+// starts on bank 0 (stride 1 KiB), so they would collide two ways; instances 2, 3 (6, 7) of a wave therefore keep their
+// register pairs in the order jj ^ 1 (SW = 1): the same rows, the other 128-byte half of the 256-byte bank line.
+#define ROWJ(j) (((((j) >> 1) & 1) ? rbO : rbE) + 2 * G * ((j) >> 1) + ((j) & 1))
 #define ROW_OWNER(r) ((((r) >> 1) & (G - 1)) == g)
-#define ROW_BIT(r) ((((r) / (2 * G)) << 1) | ((r) & 1))
+#define ROW_BIT(r) (((((r) / (2 * G)) ^ SW) << 1) | ((r) & 1))
 
 #define OCT_LAYOUT \
     extern __shared__ __attribute__((aligned(16))) char smem[]; \
@@ -145,11 +148,13 @@ __device__ __forceinline__ double frcp(double x) {
     constexpr int NS = KMAX / G; \
     constexpr int RPL = 2 * RP; \
     constexpr int NQ = 2 * G * RP; \
-    constexpr int LD = NQ | 1; \
+    constexpr int LD = NQ; \
     constexpr int CH = (G >= 32) ? OCT_CH32 : 4, XCH = (G >= 32) ? OCT_XCH32 : 2; \
     const int n = p.n, nx = p.nx; \
     const int tid = threadIdx.x, g = tid & (G - 1), li = tid / G; \
     [[maybe_unused]] const int lane = tid & 63; \
+    const int SW = (G == 8 && !(RP & 1)) ? ((li >> 1) & 1) : 0; \
+    [[maybe_unused]] const int rbE = 2 * g + 2 * G * SW, rbO = 2 * g - 2 * G * SW; \
     double* sHi = reinterpret_cast<double*>(smem); \
     double* sLb = sHi + (size_t)n * LD; \
     double* sUb = sLb + NQ; \
@@ -462,11 +467,14 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             if (!__any(cb < khi)) break;
             double la[XCH]; int oa[XCH];
 #pragma unroll
-            for (int u = 0; u < XCH; ++u) { la[u] = myR[cb + u]; oa[u] = myA[cb + u] * LD + 2 * g; }
+            for (int u = 0; u < XCH; ++u) { la[u] = myR[cb + u]; oa[u] = myA[cb + u] * LD; }
 #pragma unroll
             for (int u = 0; u < XCH; ++u)
 #pragma unroll
-                for (int j = 0; j < RPL; ++j) x[j] -= sHi[oa[u] + COLJ(j)] * la[u];
+                for (int jj = 0; jj < RP; ++jj) {
+                    const double2 hv = *reinterpret_cast<const double2*>(sHi + oa[u] + ROWJ(2 * jj));
+                    x[2 * jj] -= hv.x * la[u]; x[2 * jj + 1] -= hv.y * la[u];
+                }
         }
         wsync();
     };
@@ -477,7 +485,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         wsync();
         int ro[NS];
 #pragma unroll
-        for (int i = 0; i < NS; ++i) ro[i] = raO[i] * LD;
+        for (int i = 0; i < NS; ++i) ro[i] = raO[i];
 #pragma unroll
         for (int cb = 0; cb < KMAX; cb += CH) {
             if (!__any(cb < khi)) break;
@@ -487,7 +495,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #pragma unroll
             for (int u = 0; u < CH; ++u)
 #pragma unroll
-                for (int i = 0; i < NS; ++i) e[i] -= sHi[ro[i] + rw[u]] * lv[u];
+                for (int i = 0; i < NS; ++i) e[i] -= sHi[rw[u] * LD + ro[i]] * lv[u];      // Hi is symmetric
         }
 #pragma unroll
         for (int i = 0; i < NS; ++i) if (sgO[i] == 0.0) e[i] = 0.0;
@@ -627,20 +635,25 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             wsync();
             const double cp = t * sp;
             {
-                const int op = po + 2 * g;
 #pragma unroll
-                for (int j = 0; j < RPL; ++j) x[j] -= cp * sHi[op + COLJ(j)];
+                for (int jj = 0; jj < RP; ++jj) {
+                    const double2 hv = *reinterpret_cast<const double2*>(sHi + po + ROWJ(2 * jj));
+                    x[2 * jj] -= cp * hv.x; x[2 * jj + 1] -= cp * hv.y;
+                }
             }
 #pragma unroll
             for (int cb = 0; cb < KMAX; cb += XCH) {
                 if (!__any(cb < khi)) break;
                 double ca[XCH]; int oa[XCH];
 #pragma unroll
-                for (int u = 0; u < XCH; ++u) { ca[u] = cp * myR[cb + u]; oa[u] = myA[cb + u] * LD + 2 * g; }
+                for (int u = 0; u < XCH; ++u) { ca[u] = cp * myR[cb + u]; oa[u] = myA[cb + u] * LD; }
 #pragma unroll
                 for (int u = 0; u < XCH; ++u)
 #pragma unroll
-                    for (int j = 0; j < RPL; ++j) x[j] += ca[u] * sHi[oa[u] + COLJ(j)];
+                    for (int jj = 0; jj < RP; ++jj) {
+                        const double2 hv = *reinterpret_cast<const double2*>(sHi + oa[u] + ROWJ(2 * jj));
+                        x[2 * jj] += ca[u] * hv.x; x[2 * jj + 1] += ca[u] * hv.y;
+                    }
             }
 #pragma unroll
             for (int i = 0; i < NS; ++i) lam[i] -= cp * r[i];
@@ -895,7 +908,7 @@ __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
 
 template <int G, int RP, int KMAX, int THREADS, bool COLD>
 int launch_oct_c(const PolParams& p, int ninst, hipStream_t st) {
-    constexpr int NQ = 2 * G * RP, LD = NQ | 1, IPW = THREADS / G;
+    constexpr int NQ = 2 * G * RP, LD = NQ, IPW = THREADS / G;
     if (!p.Cq) return -1;
     const size_t x0s = (size_t)IPW * p.nx * 8;
     const size_t xch = (size_t)IPW * KMAX * 20;
