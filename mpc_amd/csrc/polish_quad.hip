@@ -163,9 +163,10 @@ __device__ __forceinline__ double frcp(double x) {
     double* sKu = sD + 3 * NQ; \
     double* sStage = sKu + (size_t)(nx + 1) * NQ; \
     double* sX0 = sStage; \
-    double* myR = sStage + (size_t)li * KMAX; \
-    double* myV = sStage + (size_t)(IPW + li) * KMAX; \
-    int* myA = reinterpret_cast<int*>(sStage + (size_t)2 * IPW * KMAX) + li * KMAX; \
+    constexpr int KST = KMAX + 4; \
+    double* myR = sKu + (size_t)li * KST; \
+    double* myV = sKu + (size_t)(IPW + li) * KST; \
+    int* myA = reinterpret_cast<int*>(sKu + (size_t)2 * IPW * KST) + li * KST; \
 
 
 // one block of IPW instances: the whole active-set solve
@@ -251,7 +252,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             }
         }
     }
-    __syncthreads();       // the stage area becomes the exchange scratch
+    __syncthreads();       // the map and x0 are dead: their space becomes the exchange scratch
 #pragma unroll
     for (int i = 0; i < NS; ++i) { myR[G * i + g] = 0.0; myV[G * i + g] = 0.0; myA[G * i + g] = 0; }
     wsync();
@@ -911,8 +912,12 @@ int launch_oct_c(const PolParams& p, int ninst, hipStream_t st) {
     constexpr int NQ = 2 * G * RP, LD = NQ, IPW = THREADS / G;
     if (!p.Cq) return -1;
     const size_t x0s = (size_t)IPW * p.nx * 8;
-    const size_t xch = (size_t)IPW * KMAX * 20;
-    const size_t lds = ((size_t)p.n * LD + 5 * NQ + (size_t)(p.nx + 1) * NQ) * 8 + (x0s > xch ? x0s : xch);
+    // the exchange arrays of the instances (r, v: doubles, the row list: ints) take the place of the map Ku1 and of x0 once the
+    // unconstrained minimiser is formed; KMAX + 4 entries apart, so that the instances of a wave read their (broadcast)
+    // entries from different banks -- KMAX apart, every other instance of the wave sat on the same ones
+    const size_t xch = (size_t)IPW * (KMAX + 4) * 20;
+    const size_t kux = (size_t)(p.nx + 1) * NQ * 8 + x0s;
+    const size_t lds = ((size_t)p.n * LD + 5 * NQ) * 8 + (kux > xch ? kux : xch);
     if (lds > 160 * 1024) return -1;
     hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS, COLD>), lds);
     if (e != hipSuccess) return (int)e;
