@@ -245,19 +245,26 @@ __device__ __forceinline__ void wave_sync() {
 // references in LDS instead of loads inside the chain, and dropping the mirrored stores (0.137 ms) all left it where it is.
 // What would help is several models per wave, which the 10 KB of LDS per model do not allow at a useful occupancy.
 // (Reference: the same cost and prediction model, LaunchPlannerQPFormulation.py:49-89,130-162; HelperFuncs.py:6-11.)
-template <int NX>
-__global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
+// MPW models per wave (4 when the NX x NX recursions need 16 lanes or fewer: they are the longer part of the kernel and kept
+// 16 of 64 lanes busy with one model per wave), LPM = 64 / MPW lanes per model; `per` doubles of LDS per model.
+// NU: the number of inputs when it is 1, 2 or 4 (loops over it unroll and the divisions by it are by a constant), 0 = a.nu
+template <int NX, int MPW, int NU>
+__global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a, int n_models, int per) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int XX = NX * NX;
-    const int lane = threadIdx.x, m = blockIdx.x;
-    const int nu = a.nu, N = a.N, n = a.n, nA = a.tv ? N : 1, XU = NX * nu;
-    const double* Am = a.A + (size_t)m * nA * XX;
-    const double* Bm = a.B + (size_t)m * nA * XU;
-    double* Phi = a.Phi + (size_t)m * a.p * NX;
-    double* H = a.H + (size_t)m * n * n;
-    double* F = a.F + (size_t)m * n * NX;
-    double* f0 = a.f0 + (size_t)m * n;
-    double* sA = reinterpret_cast<double*>(smem);       // nA x (NX, NX)
+    constexpr int XX = NX * NX, LPM = 64 / MPW;
+    static_assert(XX <= LPM, "the NX x NX recursions take one lane per element");
+    const int q = threadIdx.x / LPM, lane = threadIdx.x % LPM;
+    const int m = blockIdx.x * MPW + q;
+    const bool live = m < n_models;
+    const int mm = live ? m : 0;                        // a dead group computes model 0 again and stores nothing
+    const int nu = NU ? NU : a.nu, N = a.N, n = a.n, nA = a.tv ? N : 1, XU = NX * nu;
+    const double* Am = a.A + (size_t)mm * nA * XX;
+    const double* Bm = a.B + (size_t)mm * nA * XU;
+    double* Phi = a.Phi + (size_t)mm * a.p * NX;
+    double* H = a.H + (size_t)mm * n * n;
+    double* F = a.F + (size_t)mm * n * NX;
+    double* f0 = a.f0 + (size_t)mm * n;
+    double* sA = reinterpret_cast<double*>(smem) + (size_t)q * per;       // nA x (NX, NX)
     double* sB = sA + nA * XX;                          // nA x (NX, nu)
     double* sQ = sB + nA * XU;                          // Q, terminal P
     double* sR = sQ + 2 * XX;                           // (nu, nu)
@@ -267,14 +274,42 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
     double* ss = sT + XX;                               // 2 x NX: s_k, ping-pong
     double* sxr = ss + 2 * NX;                          // (N, NX), (N, nu): the model's references -- nothing inside the
     double* sur = sxr + N * NX;                         // backward chain may wait on global memory
-    const double* xr = a.xref ? a.xref + (size_t)m * a.xref_stride : nullptr;
-    const double* ur = a.uref ? a.uref + (size_t)m * a.uref_stride : nullptr;
-    for (int i = lane; i < N * NX; i += 64) sxr[i] = xr ? xr[i] : 0.0;
-    for (int i = lane; i < N * nu; i += 64) sur[i] = ur ? ur[i] : 0.0;
-    for (int i = lane; i < nA * XX; i += 64) sA[i] = Am[i];
-    for (int i = lane; i < nA * XU; i += 64) sB[i] = Bm[i];
-    for (int i = lane; i < XX; i += 64) { sQ[i] = a.Q[i]; sQ[XX + i] = a.P[i]; }
-    for (int i = lane; i < nu * nu; i += 64) sR[i] = a.R[i];
+    const double* xr = a.xref ? a.xref + (size_t)mm * a.xref_stride : nullptr;
+    const double* ur = a.uref ? a.uref + (size_t)mm * a.uref_stride : nullptr;
+    {   // the model into LDS with every load in flight before the first LDS write waits for one: as plain loops the compiler
+        // waited for each element before loading the next (38 round trips to memory per model with 16 lanes, a quarter of
+        // the kernel's time with 64)
+        constexpr int UA = 24, UB = 16, UX = 8, UU = 4;
+        const int cA = nA * XX, cB = nA * XU, cX = N * NX, cU = N * nu;
+        double vA[UA], vB[UB], vX[UX], vU[UU];
+#pragma unroll
+        for (int u = 0; u < UA; ++u) { const int i = lane + u * LPM; vA[u] = i < cA ? Am[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const int i = lane + u * LPM; vB[u] = i < cB ? Bm[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < UX; ++u) { const int i = lane + u * LPM; vX[u] = (xr && i < cX) ? xr[i] : 0.0; }
+#pragma unroll
+        for (int u = 0; u < UU; ++u) { const int i = lane + u * LPM; vU[u] = (ur && i < cU) ? ur[i] : 0.0; }
+        double vq = 0.0, vp = 0.0, vr = 0.0;
+        if (lane < XX) { vq = a.Q[lane]; vp = a.P[lane]; }
+        if (lane < nu * nu) vr = a.R[lane];
+#pragma unroll
+        for (int u = 0; u < UA; ++u) { const int i = lane + u * LPM; if (i < cA) sA[i] = vA[u]; }
+#pragma unroll
+        for (int u = 0; u < UB; ++u) { const int i = lane + u * LPM; if (i < cB) sB[i] = vB[u]; }
+#pragma unroll
+        for (int u = 0; u < UX; ++u) { const int i = lane + u * LPM; if (i < cX) sxr[i] = vX[u]; }
+#pragma unroll
+        for (int u = 0; u < UU; ++u) { const int i = lane + u * LPM; if (i < cU) sur[i] = vU[u]; }
+        if (lane < XX) { sQ[lane] = vq; sQ[XX + lane] = vp; }
+        if (lane < nu * nu) sR[lane] = vr;
+        // what the batches above do not cover (long horizons)
+        for (int i = lane + UA * LPM; i < cA; i += LPM) sA[i] = Am[i];
+        for (int i = lane + UB * LPM; i < cB; i += LPM) sB[i] = Bm[i];
+        for (int i = lane + UX * LPM; i < cX; i += LPM) sxr[i] = xr ? xr[i] : 0.0;
+        for (int i = lane + UU * LPM; i < cU; i += LPM) sur[i] = ur ? ur[i] : 0.0;
+        for (int i = lane + LPM; i < nu * nu; i += LPM) sR[i] = a.R[i];
+    }
     wave_sync();
     const int er = lane / NX, ec = lane % NX;           // lane < XX: element (er, ec) of the NX x NX recursions
     // ---- backward: P_k, V_k = P_k B_k, s_k; rows of f0 of stage k as soon as s_k exists ---------------------------------------
@@ -310,19 +345,19 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
         }
         wave_sync();
         const double* Bk = sB + (a.tv ? k * XU : 0);
-        for (int e = lane; e < XU; e += 64) {                       // V_k = P_k B_k  (NX, nu)
+        for (int e = lane; e < XU; e += LPM) {                      // V_k = P_k B_k  (NX, nu)
             const int r = e / nu, c = e - r * nu;
             double v = 0.0;
 #pragma unroll
             for (int b = 0; b < NX; ++b) v += Pk[r * NX + b] * Bk[b * nu + c];
             sV[k * XU + e] = v;
         }
-        for (int r = lane; r < nu; r += 64) {                       // f0 rows of stage k
+        for (int r = lane; r < nu; r += LPM) {                      // f0 rows of stage k
             double v = 0.0;
 #pragma unroll
             for (int b = 0; b < NX; ++b) v -= Bk[b * nu + r] * sk[b];
             for (int j = 0; j < nu; ++j) v -= sR[r * nu + j] * sur[k * nu + j];
-            f0[k * nu + r] = v;
+            if (live) f0[k * nu + r] = v;
         }
     }
     wave_sync();
@@ -341,39 +376,51 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
                 for (int b = 0; b < NX; ++b) v += Ak[er * NX + b] * p1[b * NX + ec];
             }
             pk[lane] = v;
-            Phi[(size_t)(k * NX + er) * NX + ec] = v;
+            if (live) Phi[(size_t)(k * NX + er) * NX + ec] = v;
         }
         wave_sync();
         const double* Vk = sV + k * XU;
-        for (int e = lane; e < nu * NX; e += 64) {                  // F rows of stage k: V_k' Phi_k
+        for (int e = lane; e < nu * NX; e += LPM) {                 // F rows of stage k: V_k' Phi_k
             const int r = e / NX, c = e % NX;
             double v = 0.0;
 #pragma unroll
             for (int b = 0; b < NX; ++b) v += Vk[b * nu + r] * pk[b * NX + c];
-            F[(size_t)(k * nu + r) * NX + c] = v;
+            if (live) F[(size_t)(k * nu + r) * NX + c] = v;
         }
     }
     wave_sync();
     // ---- columns of H -----------------------------------------------------------------------------------------------------
-    for (int col = lane; col < n; col += 64) {
-        const int j = col / nu, c = col - j * nu;
+    // Every lane of a model walks the stages in the SAME order i = jtop .. 0 and joins at its own stage j: the reads of
+    // A_i, B_i are then one address per model (a broadcast) instead of one matrix per lane on two sets of banks
+    // (a chain per lane, i = j .. 0, had the lanes of a wave in 20 different stages at once: 4 M conflict cycles per launch)
+    for (int col0 = 0; col0 < n; col0 += LPM) {
+        const int col = col0 + lane;
+        const bool on = col < n;
+        const int j = on ? col / nu : -1, c = on ? col - j * nu : 0;
         double v[NX];
 #pragma unroll
-        for (int r = 0; r < NX; ++r) v[r] = sV[j * XU + r * nu + c];
-        for (int i = j; i >= 0; --i) {
+        for (int r = 0; r < NX; ++r) v[r] = 0.0;
+        const int jtop = (min(n, col0 + LPM) - 1) / nu;
+        for (int i = jtop; i >= 0; --i) {
             const double* Bi = sB + (a.tv ? i * XU : 0);
             const double* Ai = sA + (a.tv ? i * XX : 0);
+            if (i == j) {
+#pragma unroll
+                for (int r = 0; r < NX; ++r) v[r] = sV[j * XU + r * nu + c];
+            }
             // the diagonal block is written from its upper triangle only, so that every entry of H has one writer and the
             // matrix is exactly symmetric
-            const int rmax = i == j ? c : nu - 1;
-            for (int r = 0; r <= rmax; ++r) {
+            const int rmax = i == j ? c : (i < j ? nu - 1 : -1);
+            for (int r = 0; r < nu; ++r) {
                 double hv = 0.0;
 #pragma unroll
                 for (int b = 0; b < NX; ++b) hv += Bi[b * nu + r] * v[b];
-                if (i == j) hv += sR[r * nu + c];
-                const int row = i * nu + r;
-                H[(size_t)row * n + col] = hv;
-                H[(size_t)col * n + row] = hv;
+                if (r <= rmax && live) {
+                    if (i == j) hv += sR[r * nu + c];
+                    const int row = i * nu + r;
+                    H[(size_t)row * n + col] = hv;
+                    H[(size_t)col * n + row] = hv;
+                }
             }
             if (i > 0) {
                 double w[NX];
@@ -391,12 +438,28 @@ __global__ __launch_bounds__(64) void assemble_wave_kernel(AsmParams a) {
     }
 }
 
-template <int NX>
-int launch_assemble_wave_nx(mpcqp_handle h, const AsmParams& a, size_t lds, hipStream_t st) {
-    hipError_t e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&assemble_wave_kernel<NX>), lds);
+template <int NX, int NU>
+int launch_assemble_wave_nu(mpcqp_handle h, const AsmParams& a, size_t lds_model, hipStream_t st) {
+    constexpr int MPW = NX * NX <= 16 ? 4 : (NX * NX <= 32 ? 2 : 1);
+    // regions 16 (mod 32) doubles apart: the two models a 32-lane LDS cycle serves (lanes 0-31, 32-63) read the same offsets
+    // of their regions, 128 bytes wide, and must fall on the two halves of the 256-byte bank line
+    int per = (int)(lds_model / sizeof(double));
+    per += (16 - per % 32 + 32) % 32;
+    const size_t lds = (size_t)MPW * per * sizeof(double);
+    hipError_t e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&assemble_wave_kernel<NX, MPW, NU>), lds);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return MPCQP_EHIP; }
-    hipLaunchKernelGGL(assemble_wave_kernel<NX>, dim3(h->dims.n_models), dim3(64), lds, st, a);
+    hipLaunchKernelGGL((assemble_wave_kernel<NX, MPW, NU>), dim3(ceil_div(h->dims.n_models, MPW)), dim3(64), lds, st, a, h->dims.n_models, per);
     return MPCQP_OK;
+}
+
+template <int NX>
+int launch_assemble_wave_nx(mpcqp_handle h, const AsmParams& a, size_t lds_model, hipStream_t st) {
+    switch (a.nu) {
+        case 1: return launch_assemble_wave_nu<NX, 1>(h, a, lds_model, st);
+        case 2: return launch_assemble_wave_nu<NX, 2>(h, a, lds_model, st);
+        case 4: return launch_assemble_wave_nu<NX, 4>(h, a, lds_model, st);
+        default: return launch_assemble_wave_nu<NX, 0>(h, a, lds_model, st);
+    }
 }
 
 }  // namespace
