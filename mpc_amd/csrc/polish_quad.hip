@@ -961,6 +961,7 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
     const int n = p.n, nx = p.nx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 15, kq = lane >> 4;
     const int KS = (nx + 1 + 3) / 4, KP = 4 * KS, NQ = 16 * ((n + 15) / 16);
+    const int XS = KP + 1;      // odd stride of the [x0; 1] rows: the 16 instances of a tile read theirs from different banks
     double* sKu = reinterpret_cast<double*>(smem);      // (KP, NQ): Ku1 transposed, zero padded
     double* sLb = sKu + (size_t)KP * NQ;                // (NQ) padded rows can never be violated
     double* sUb = sLb + NQ;
@@ -986,35 +987,47 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
     {
         constexpr int U = 4;
         for (int base = tid; base < 64 * KP; base += U * 256) {
-            double v[U];
+            double v[U]; int off[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int idx = base + u * 256;
                 const int l = idx / KP, k = idx - l * KP;
                 const int i2 = blockIdx.x * 64 + l;
+                off[u] = l * XS + k;
                 v[u] = (idx < 64 * KP && i2 < p.B) ? (k < nx ? p.x0[(size_t)i2 * nx + k] : (k == nx ? 1.0 : 0.0)) : 0.0;
             }
 #pragma unroll
-            for (int u = 0; u < U; ++u) if (base + u * 256 < 64 * KP) sX[base + u * 256] = v[u];
+            for (int u = 0; u < U; ++u) if (base + u * 256 < 64 * KP) sX[off[u]] = v[u];
         }
     }
     if (tid < NBIN) hist[tid] = 0;
     __syncthreads();
     const int inst = blockIdx.x * 64 + wave * 16 + col;
-    const double* xrow = sX + (size_t)(wave * 16 + col) * KP;
+    const double* xrow = sX + (size_t)(wave * 16 + col) * XS;
     int cnt = 0;
-    for (int t = 0; t < NQ / 16; ++t) {
-        d4 acc = {0, 0, 0, 0};
-        for (int s = 0; s < KS; ++s) {
-            const int k = 4 * s + kq;
-            acc = mfma_f64(sKu[k * NQ + 16 * t + col], xrow[k], acc);
-        }
+    // all (up to 8) row tiles of the map at once: one read of [x0; 1] per k-step serves them, their LDS reads are issued
+    // together and the MFMAs follow each other on independent accumulators (tile by tile every MFMA waited for its own two
+    // LDS reads: 17 k of the kernel's 25 k cycles per workgroup)
+    const int NT = NQ / 16;
+    d4 acc[8];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = 16 * t + kq + 4 * r;
-            cnt += (acc[r] > sUb[row]) | (acc[r] < sLb[row]);
-        }
+    for (int t = 0; t < 8; ++t) acc[t] = d4{0, 0, 0, 0};
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + kq;
+        const double xv = xrow[k];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < NT) acc[t] = mfma_f64(sKu[k * NQ + 16 * t + col], xv, acc[t]);
     }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < NT) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * t + kq + 4 * r;
+                cnt += (acc[t][r] > sUb[row]) | (acc[t][r] < sLb[row]);
+            }
+        }
     cnt += __shfl_xor(cnt, 16);
     cnt += __shfl_xor(cnt, 32);
     if (kq == 0 && inst < p.B) {
@@ -1071,7 +1084,7 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
     a.hand_in = nullptr; a.hand_out = p.cold ? p.hand_buf1 : nullptr; a.hand_out_cap = p.B; a.hand_zw = 0;
     const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
-    const size_t kl = ((size_t)kp * nq + 2 * nq + 64 * (size_t)kp) * sizeof(double);
+    const size_t kl = ((size_t)kp * nq + 2 * nq + 64 * (size_t)(kp + 1)) * sizeof(double);
     // the ordering pays once the device is full (lock-step efficiency); below that a launch lasts as long as its heaviest
     // block either way and the two extra kernels only add to it (measured, per solve: 32,768 instances 276 us with / 322 us
     // without; 16,384: 242 / 223; 8,192: 219 / 200)
