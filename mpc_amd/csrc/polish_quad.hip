@@ -705,6 +705,15 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #pragma unroll
         for (int i = 0; i < NS; ++i) need = need || fabs(e[i]) > 1e-13 * fmax(1.0, fabs(rhs[i]));
         if (!__any(need && run)) break;
+        // the correction is the instance's own business: one that does not need it must not receive a rounding-level one because
+        // a neighbour in the wave does (which instances share a wave changes from solve to solve with the cold-start order,
+        // and the results are meant to be reproducible bit for bit)
+        const unsigned long long nb = __ballot(need && run);
+        const bool mine = G == 64 ? nb != 0ull : ((nb >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1ull)) != 0ull;
+        if (!mine) {
+#pragma unroll
+            for (int i = 0; i < NS; ++i) e[i] = 0.0;
+        }
         w_times(e, dl);
 #pragma unroll
         for (int i = 0; i < NS; ++i) lam[i] += dl[i];

@@ -210,6 +210,35 @@ def test_no_sync_factor_failure_is_reported_as_status():
         assert (pl.info.status.cpu().numpy() == _lib.SOLVED).all()
 
 
+def test_two_handles_on_two_streams_do_not_disturb_each_other():
+    """The serving pattern bench.py reports beside `value`: two handles, two streams, solves in flight together.  Every
+    handle owns its queues, counters and hand-over records, so the answers are those of the same solves one by one
+    (bit for bit: the cascade is deterministic per instance)."""
+    import torch
+    from mpc_amd.configs import make_config
+    probs = [make_config(3, batch=30000, seed=5), make_config(3, batch=26000, seed=6)]
+    pls = [_planner(p).setup() for p in probs]
+    xs = [torch.as_tensor(1.4 * p["x0"], device="cuda:0") for p in probs]       # long queues in every pass
+    ref = [pl.solve(x).clone() for pl, x in zip(pls, xs)]
+    # reproducible bit for bit from solve to solve, although the cold-start order (atomic cursors) puts an instance next to
+    # different neighbours every time: nothing an instance computes may depend on the other instances of its wave
+    for pl, x, r in zip(pls, xs, ref):
+        assert torch.equal(pl.solve(x), r)
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    for pl in pls:
+        pl.reuse_outputs = True
+    outs = [None, None]
+    for rep in range(6):
+        for i in (0, 1):
+            with torch.cuda.stream(streams[i]):
+                outs[i] = pls[i].solve(xs[i])
+    torch.cuda.synchronize()
+    for i in (0, 1):
+        assert int((pls[i].info.status != 0).sum()) == 0
+        assert torch.equal(outs[i], ref[i])
+
+
 def test_reuse_outputs_returns_the_same_buffers_with_fresh_results():
     """Planner.reuse_outputs (serving loops, bench.py): no allocation per call -- same U / info tensors, new contents."""
     import torch
