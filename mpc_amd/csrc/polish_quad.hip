@@ -366,15 +366,20 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         bool wact = valid;
         if (wact && k0 > KMAX) { over = true; why = 1; wact = false; }
         if (wact) {
+            // list positions in ROW order, whatever the order of the lane's registers (SW swaps its row pairs two by two):
+            // the order of the list is the order of the bordering, and the result must not depend on the instance's place
+            // in the wave
+            const unsigned mo = SW ? (((m & 0x33333333u) << 2) | ((m >> 2) & 0x33333333u)) : m;
 #pragma unroll
             for (int j = 0; j < RPL; ++j)
                 if ((m >> j) & 1u) {
                     const int row = ROWJ(j);
                     const bool up = (mU >> j) & 1u;
-                    myA[off] = row;
-                    myR[off] = up ? 1.0 : -1.0;
-                    myV[off] = x[j] - (up ? sUb[row] : sLb[row]);
-                    ++off;
+                    const int bj = SW ? (j ^ 2) : j;
+                    const int pos = off + __popc(mo & ((1u << bj) - 1u));
+                    myA[pos] = row;
+                    myR[pos] = up ? 1.0 : -1.0;
+                    myV[pos] = x[j] - (up ? sUb[row] : sLb[row]);
                 }
         }
         wsync();
