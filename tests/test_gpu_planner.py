@@ -255,6 +255,41 @@ def test_an_instance_does_not_depend_on_its_neighbours(kw):
     assert torch.equal(Ub, Ua[perm])
 
 
+def test_two_host_threads_with_their_own_handles():
+    """Two host threads, each with its own handle and stream, inside the library at the same time (ctypes releases the
+    GIL): the library's only process-wide state is the mutex-guarded table of kernel attributes."""
+    import threading
+    import torch
+    from mpc_amd.configs import make_config
+    probs = [make_config(3, batch=20000, seed=8), make_config(2, batch=3000, seed=9)]
+    pls = [_planner(p).setup() for p in probs]
+    xs = [torch.as_tensor(1.3 * p["x0"], device="cuda:0") for p in probs]
+    ref = [pl.solve(x).clone() for pl, x in zip(pls, xs)]
+    torch.cuda.synchronize()
+    errs = []
+
+    def work(i):
+        try:
+            torch.cuda.set_device(0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for _ in range(20):
+                    U = pls[i].solve(xs[i])
+                st.synchronize()
+                if not torch.equal(U, ref[i]) or int((pls[i].info.status != 0).sum()):
+                    errs.append(f"thread {i}: result differs from the single-threaded solve")
+        except Exception as e:      # noqa: BLE001
+            errs.append(f"thread {i}: {type(e).__name__}: {e}")
+
+    th = [threading.Thread(target=work, args=(i,)) for i in (0, 1)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errs, errs
+    assert not any(t.is_alive() for t in th)
+
+
 def test_reuse_outputs_returns_the_same_buffers_with_fresh_results():
     """Planner.reuse_outputs (serving loops, bench.py): no allocation per call -- same U / info tensors, new contents."""
     import torch
