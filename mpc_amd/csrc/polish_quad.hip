@@ -965,6 +965,9 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 // an ADMM iterate the number of bounds the unconstrained minimiser violates predicts the number of active-set steps:
 // instances are bucketed by that count (32 buckets, largest first) and the first pass reads them through the queue.
 constexpr int NBIN = 32;
+// every bucket's count and cursor on a cache line of their own: the 1,024 workgroups of the key kernel add to them at the
+// end, and ~20 k atomics on ONE line were what the launch waited for after its last workgroup had finished computing
+constexpr int BIN_STRIDE = 32;
 constexpr int SMALL_BATCH = 8192;
 
 // xu = Ku1 [x0; 1] for 16 instances per wave on fp64 MFMA tiles (A = 16 rows of Ku1, B = [x0; 1] of 16 instances), the
@@ -1050,7 +1053,7 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
         atomicAdd(&hist[key], 1);
     }
     __syncthreads();
-    if (tid < NBIN && hist[tid]) atomicAdd(&bins[tid], hist[tid]);
+    if (tid < NBIN && hist[tid]) atomicAdd(&bins[tid * BIN_STRIDE], hist[tid]);
 }
 
 // Buckets >= route go straight to the second pass (its queue q1 / *q1_count): measured on BASELINE configs[2] the final
@@ -1065,12 +1068,12 @@ __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, cons
         hist[tid] = 0;
         int run = 0;                // instances of the same class (routed / first pass) in the buckets above mine
         const int top = tid >= route ? NBIN : route;
-        for (int k = tid + 1; k < top; ++k) run += bins[k];
+        for (int k = tid + 1; k < top; ++k) run += bins[k * BIN_STRIDE];
         start[tid] = run;
     }
     if (blockIdx.x == 0 && tid == 0) {
         int a = 0, b = 0;
-        for (int k = 0; k < NBIN; ++k) (k >= route ? b : a) += bins[k];
+        for (int k = 0; k < NBIN; ++k) (k >= route ? b : a) += bins[k * BIN_STRIDE];
         *count = a;
         *q1_count = b;              // the first pass appends what it cannot finish behind the routed ones
     }
@@ -1078,7 +1081,7 @@ __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, cons
     int key = 0, local = 0;
     if (inst < B) { key = keys[inst]; local = atomicAdd(&hist[key], 1); }
     __syncthreads();
-    if (tid < NBIN && hist[tid]) base[tid] = start[tid] + atomicAdd(&cursors[tid], hist[tid]);
+    if (tid < NBIN && hist[tid]) base[tid] = start[tid] + atomicAdd(&cursors[tid * BIN_STRIDE], hist[tid]);
     __syncthreads();
     if (inst < B) {
         (key >= route ? q1 : order)[base[key] + local] = inst;
@@ -1092,7 +1095,7 @@ __global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, cons
 // Returns 0 on launch, -1 if the shape does not fit this path, a hipError_t (> 0) otherwise.
 int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipStream_t st, int stop_after) {
     if (!p.polish || p.refine > 0 || p.nx > 64 || p.n > 128) return -1;
-    hipError_t e = hipMemsetAsync(counters, 0, 96 * sizeof(int), st);       // queue counters, buckets, cursors
+    hipError_t e = hipMemsetAsync(counters, 0, (96 + NBIN * BIN_STRIDE) * sizeof(int), st);       // queue counters, buckets, cursors
     if (e != hipSuccess) return (int)e;
     PolParams a = p;
     a.qin = nullptr; a.qin_count = nullptr; a.qout = q1; a.qout_count = counters;
@@ -1105,8 +1108,8 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (p.cold && p.B >= 24576 && kl <= 64 * 1024) {
         // keys in q2 (written again only by the second pass), buckets / cursors / count in the counter block,
         // the order in the last slot of the int workspace
-        int* keys = q2; int* order = counters + 96;
-        int* bins = counters + 16; int* cursors = bins + NBIN; int* count = counters + 2;
+        int* keys = q2; int* order = counters + 96 + NBIN * BIN_STRIDE;
+        int* bins = counters + 96; int* cursors = bins + 1; int* count = counters + 2;
         hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins);
         // routing past the first pass (buckets >= route start in the second): worth it only while an instance that outgrows
         // the first pass has to start again (warm solves: first-pass capacity 16 rows, final set ~1.5 x key; swept 8..14: 10 is
