@@ -38,7 +38,7 @@ int ensure_batch(mpcqp_handle h, int B) {
     TRY(dev_alloc(h, &h->z, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->w, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->b0ws, (size_t)need * h->NP));
-    TRY(dev_alloc(h, &h->it_ws, (size_t)need * 6 + 96 + 1024));   // iters | need_big | converged | queue 1 | queue 2 | counters | buckets (32 x 32) | cold-start order
+    TRY(dev_alloc(h, &h->it_ws, (size_t)need * (5 + 32) + 96 + 1024));   // iters | need_big | converged | queue 1 | queue 2 | counters | bucket sizes (32 x 32) | the 32 buckets of the cold-start order
     TRY(dev_alloc(h, &h->rp_ws, (size_t)need));
     TRY(dev_alloc(h, &h->rd_ws, (size_t)need));
     TRY(dev_alloc(h, &h->hbuf1, (size_t)need * (16 * 16 + 4 * 16 + 2)));

@@ -37,6 +37,8 @@ struct PolParams {
     int q_gate;                    // > 0: run only if the queue holds at least this many; < 0: only if fewer than -q_gate; 0: always
     int cold; int admm_ran; const double* Cq;                      // 1: no (z, w) to start from -- begin with the empty active set
     const int *qin, *qin_count;    // instance queue to take the work from (nullptr: instances 0..B-1)
+    const int *seg, *seg_counts;   // cold-start order without a scatter pass: bucket k's instances in seg[k * B ..], its size in
+                                   // seg_counts[32 k]; the place p of the order (largest bucket first) is looked up by the reader
     int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)
     unsigned long long* prof;      // debugging only (POLISH_PROF builds): per-phase cycle sums, else nullptr
 };

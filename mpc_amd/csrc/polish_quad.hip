@@ -142,6 +142,11 @@ __device__ __forceinline__ double frcp(double x) {
 #define ROW_OWNER(r) ((((r) >> 1) & (G - 1)) == g)
 #define ROW_BIT(r) (((((r) / (2 * G)) ^ SW) << 1) | ((r) & 1))
 
+constexpr int NBIN = 32;
+// every bucket's count and cursor on a cache line of their own: the 1,024 workgroups of the key kernel add to them at the
+// end, and ~20 k atomics on ONE line were what the launch waited for after its last workgroup had finished computing
+constexpr int BIN_STRIDE = 32;
+
 #define OCT_LAYOUT \
     extern __shared__ __attribute__((aligned(16))) char smem[]; \
     constexpr int IPW = THREADS / G; \
@@ -171,7 +176,8 @@ __device__ __forceinline__ double frcp(double x) {
 
 // one block of IPW instances: the whole active-set solve
 template <int G, int RP, int KMAX, int THREADS, bool COLD>
-__device__ __forceinline__ void oct_block(const PolParams& p, const int blk, const int total, unsigned long long* pacc_out) {
+__device__ __forceinline__ void oct_block(const PolParams& p, const int blk, const int total, unsigned long long* pacc_out,
+                                          const int inst, const double (&xpre)[64 / G]) {
     OCT_LAYOUT
 #ifdef POLISH_PROF
     unsigned long long pacc[16] = {};
@@ -179,7 +185,6 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #endif
     const int slot0 = blk * IPW;
     const bool valid = slot0 + li < total;
-    const int inst = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
     // the ADMM iterate (z, w) of my rows: issued first so that the HBM latency hides behind the staging below
     double zz[RPL], ww[RPL];
 #pragma unroll
@@ -205,8 +210,9 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         }
     }
 
-    // x0 of my instance: the group's lanes fetch it themselves (the instance index is already here: no second index load)
-    for (int c = g; c < nx; c += G) sX0[li * nx + c] = valid ? p.x0[(size_t)inst * nx + c] : 0.0;
+    // x0 of my instance: fetched by the group's own lanes before the staging (oct_body)
+#pragma unroll
+    for (int u = 0; u < 64 / G; ++u) { const int c = g + u * G; if (c < nx) sX0[li * nx + c] = xpre[u]; }
     __syncthreads();
     PROF_MARK(0);
 
@@ -844,6 +850,26 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
     const int total = p.qin ? *p.qin_count : p.B;
     if ((int)blockIdx.x * IPW >= total) return;
     if ((p.q_gate > 0 && total < p.q_gate) || (p.q_gate < 0 && total >= -p.q_gate)) return;     // not this instantiation's regime
+    // my instance and its x0 BEFORE the staging: the chain place -> (bucket sizes ->) instance index -> x0 is two or three
+    // round trips to memory, which now pass while the 115 KB of Hi arrive instead of after them
+    const int blk = blockIdx.x;
+    const int slot0 = blk * IPW;
+    const bool valid = slot0 + li < total;
+    int inst = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
+    if (p.seg) {        // my place in the cold-start order (largest bucket first) -> bucket and offset, from the buckets' sizes
+        const int pos = slot0 + li;
+        int bk = 0, off = 0, acc = 0;
+#pragma unroll
+        for (int k = NBIN - 1; k >= 0; --k) {
+            const int c = p.seg_counts[k * BIN_STRIDE];
+            if (pos >= acc && pos < acc + c) { bk = k; off = pos - acc; }
+            acc += c;
+        }
+        inst = valid ? p.seg[(size_t)bk * p.B + off] : 0;
+    }
+    double xpre[64 / G];
+#pragma unroll
+    for (int u = 0; u < 64 / G; ++u) { const int c = g + u * G; xpre[u] = (valid && c < nx) ? p.x0[(size_t)inst * nx + c] : 0.0; }
     // ---- stage the shared data --------------------------------------------------------------
     {   // Hi -> LDS.  The workgroup can do nothing else until this has landed, so the loads are as wide as they can be (16 bytes,
         // contiguous over the workgroup) and all in flight before the first LDS write waits for one
@@ -906,7 +932,7 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
                 if (off[u] >= 0) *reinterpret_cast<double2*>(sKu + off[u]) = vk[u];
         }
     }
-    oct_block<G, RP, KMAX, THREADS, COLD>(p, blockIdx.x, total, pacc);
+    oct_block<G, RP, KMAX, THREADS, COLD>(p, blockIdx.x, total, pacc, inst, xpre);
 #ifdef POLISH_PROF
     if (lane == 0 && p.prof) {
         unsigned long long tot = 0;
@@ -964,15 +990,11 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 // The lanes of a wave walk their 8 (16) instances in lock-step, so a wave takes as long as its slowest instance.  Without
 // an ADMM iterate the number of bounds the unconstrained minimiser violates predicts the number of active-set steps:
 // instances are bucketed by that count (32 buckets, largest first) and the first pass reads them through the queue.
-constexpr int NBIN = 32;
-// every bucket's count and cursor on a cache line of their own: the 1,024 workgroups of the key kernel add to them at the
-// end, and ~20 k atomics on ONE line were what the launch waited for after its last workgroup had finished computing
-constexpr int BIN_STRIDE = 32;
 constexpr int SMALL_BATCH = 8192;
 
 // xu = Ku1 [x0; 1] for 16 instances per wave on fp64 MFMA tiles (A = 16 rows of Ku1, B = [x0; 1] of 16 instances), the
 // violated rows counted straight from the D registers: lane l holds rows (l>>4)+4r of instance l&15
-__global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, int* bins) {
+__global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, int* bins, int* seg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int hist[NBIN];
     const int n = p.n, nx = p.nx, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1047,46 +1069,20 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
         }
     cnt += __shfl_xor(cnt, 16);
     cnt += __shfl_xor(cnt, 32);
-    if (kq == 0 && inst < p.B) {
-        const int key = min(cnt, NBIN - 1);
-        keys[inst] = key;
-        atomicAdd(&hist[key], 1);
-    }
-    __syncthreads();
-    if (tid < NBIN && hist[tid]) atomicAdd(&bins[tid * BIN_STRIDE], hist[tid]);
-}
-
-// Buckets >= route go straight to the second pass (its queue q1 / *q1_count): measured on BASELINE configs[2] the final
-// active set is ~1.5x the key (correlation 0.92), so such instances would run the first pass up to its capacity only to
-// start again.  The others are laid out largest bucket first.  Every block derives the bucket offsets from the finished
-// histogram itself; cursors (zeroed by the caller) hand out the places inside a bucket.
-__global__ __launch_bounds__(256) void cold_scatter_kernel(const int* keys, const int* bins, int* cursors, int* order, int* q1,
-                                                           int* count, int* q1_count, int* need_big, int B, int route) {
-    __shared__ int hist[NBIN], base[NBIN], start[NBIN];
-    const int tid = threadIdx.x, inst = blockIdx.x * 256 + tid;
-    if (tid < NBIN) {
-        hist[tid] = 0;
-        int run = 0;                // instances of the same class (routed / first pass) in the buckets above mine
-        const int top = tid >= route ? NBIN : route;
-        for (int k = tid + 1; k < top; ++k) run += bins[k * BIN_STRIDE];
-        start[tid] = run;
-    }
-    if (blockIdx.x == 0 && tid == 0) {
-        int a = 0, b = 0;
-        for (int k = 0; k < NBIN; ++k) (k >= route ? b : a) += bins[k * BIN_STRIDE];
-        *count = a;
-        *q1_count = b;              // the first pass appends what it cannot finish behind the routed ones
-    }
-    __syncthreads();
+    // the instance goes straight into its bucket's own array (place = the bucket's running count: one atomic per bucket and
+    // workgroup); the first pass finds "place p of the order" from the buckets' final sizes itself -- no scatter pass
+    __shared__ int base[NBIN];
+    const bool mine = kq == 0 && inst < p.B;
     int key = 0, local = 0;
-    if (inst < B) { key = keys[inst]; local = atomicAdd(&hist[key], 1); }
-    __syncthreads();
-    if (tid < NBIN && hist[tid]) base[tid] = start[tid] + atomicAdd(&cursors[tid * BIN_STRIDE], hist[tid]);
-    __syncthreads();
-    if (inst < B) {
-        (key >= route ? q1 : order)[base[key] + local] = inst;
-        if (key >= route) need_big[inst] = 0;       // routed past the first pass: nothing is handed over in (z, w)
+    if (mine) {
+        key = min(cnt, NBIN - 1);
+        keys[inst] = key;
+        local = atomicAdd(&hist[key], 1);
     }
+    __syncthreads();
+    if (tid < NBIN && hist[tid]) base[tid] = atomicAdd(&bins[tid * BIN_STRIDE], hist[tid]);
+    __syncthreads();
+    if (mine) seg[(size_t)key * p.B + base[key] + local] = inst;
 }
 
 // The two fast passes: pass A (8 lanes per instance, KMAX = 16) takes the whole batch (large cold batches: in cold-start
@@ -1108,18 +1104,13 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     if (p.cold && p.B >= 24576 && kl <= 64 * 1024) {
         // keys in q2 (written again only by the second pass), buckets / cursors / count in the counter block,
         // the order in the last slot of the int workspace
-        int* keys = q2; int* order = counters + 96 + NBIN * BIN_STRIDE;
-        int* bins = counters + 96; int* cursors = bins + 1; int* count = counters + 2;
-        hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins);
-        // routing past the first pass (buckets >= route start in the second): worth it only while an instance that outgrows
-        // the first pass has to start again (warm solves: first-pass capacity 16 rows, final set ~1.5 x key; swept 8..14: 10 is
-        // best).  With the hand-over of cold solves every instance starts in the first pass and continues where it stopped
-        // (65,536 instances: 402 us routed at 10, 383 us unrouted with the set handed over, 375 us with the whole state)
-        const int route = a.hand_out ? NBIN : std::min(NBIN, 2 * 16 / 3);
-        hipLaunchKernelGGL(cold_scatter_kernel, dim3(ceil_div(p.B, 256)), dim3(256), 0, st, keys, bins, cursors, order, q1, count,
-                           counters, p.need_big, p.B, route);
+        int* keys = q2; int* seg = counters + 96 + NBIN * BIN_STRIDE;
+        int* bins = counters + 96;
+        hipLaunchKernelGGL(cold_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, keys, bins, seg);
+        // (Round 1 routed the heaviest buckets past the first pass, because an instance that outgrew it had to start again;
+        // with the hand-over every instance starts in the first pass and continues where it stopped: 402 us routed, 375 us not.)
         if ((e = hipGetLastError()) != hipSuccess) return (int)e;
-        a.qin = order; a.qin_count = count;
+        a.seg = seg; a.seg_counts = bins;
     }
     if (stop_after == 2) return 0;
     // A small cold batch (a 1/8 shard of the headline batch and below) lasts as long as its slowest instance, whatever the
