@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0
 # HBM bytes per launch at 65,536 instances from the committed PMC passes (2 * FETCH_SIZE + WRITE_SIZE, KB -> bytes)
 PMC = {
     "admm": ((2 * 49314.40 + 213303.90) * 1024.0, "profiles/r01_v5_pmc.csv (admm_shared_box_kernel)"),
-    "pass_a": ((2 * 7436.73 + 195137.54) * 1024.0, "profiles/r02_pmc.csv (polish_oct_kernel<8, 8, 16, 512, true>, the first pass)"),
+    "pass_a": ((2 * 7575.72 + 195238.18) * 1024.0, "profiles/r02_pmc.csv (polish_oct_kernel<8, 8, 16, 512, true>, the first pass)"),
 }
 
 
