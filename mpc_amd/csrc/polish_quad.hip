@@ -1127,7 +1127,9 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     }
     // fewer blocks of 64 instances than the device has CUs (a 1/8 shard of the headline batch): half-size workgroups, so that
     // the launch covers twice as many CUs with one wave per SIMD -- the latency of the heaviest block is what such a launch lasts
-    int rc = p.B < 64 * 256 ? launch_oct_rp<8, 16, 256>(a, p.B, st) : launch_oct_rp<8, 16, 512>(a, p.B, st);
+    // (half-size workgroups only while they still fit the device in ONE round, 32 instances x 256 CUs: between 8,193 and 16,383
+    // instances they were two rounds -- 12,288 instances took 0.220 ms, longer than 16,384 -- where the full-size ones are one)
+    int rc = p.B <= 32 * 256 ? launch_oct_rp<8, 16, 256>(a, p.B, st) : launch_oct_rp<8, 16, 512>(a, p.B, st);
     if (rc != 0 || stop_after == 1) return rc;
     PolParams b = p;
     b.qin = q1; b.qin_count = counters; b.qout = q2; b.qout_count = counters + 1;
