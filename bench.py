@@ -325,9 +325,9 @@ class BoxWorkload:
         both_ms = timed(lambda: pl.solve(x0, **opts), reps)
         # the first (and longest) active-set launch alone: stages bit 2 stops after it, bit 3 after the cold-start
         # ordering kernels that run before it (diagnostic modes: queued instances stay open)
-        # (the ordering kernels only run for cold batches of 24,576 instances or more, polish_quad.hip; below that "stages=15"
+        # (the ordering kernel only runs for cold batches of more than 16,384 instances, polish_quad.hip; below that "stages=15"
         # times an empty solve, i.e. the host's launch cost, which is not something to subtract from a kernel time)
-        ordered = B >= 24576 and not admm_on
+        ordered = B > 16384 and not admm_on
         order_ms = max(timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms, 0.0) if ordered else 0.0
         pass_a_ms = max(timed(lambda: pl.solve(x0, stages=7, **opts), reps) - admm_ms - order_ms, 0.0)
         nlat = max(20, min(args.steps, 100))

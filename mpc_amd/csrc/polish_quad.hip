@@ -1101,7 +1101,9 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
     // the ordering pays once the device is full (lock-step efficiency); below that a launch lasts as long as its heaviest
     // block either way and the two extra kernels only add to it (measured, per solve: 32,768 instances 276 us with / 322 us
     // without; 16,384: 242 / 223; 8,192: 219 / 200)
-    if (p.cold && p.B >= 24576 && kl <= 64 * 1024) {
+    // (round 2, late: the ordering kernel is one launch and 30 us now, and pays as soon as the first pass needs more than
+    // ONE round of workgroups -- 20,000 instances: 0.227 ms unordered, 0.18 ordered; 16,384, one round: 0.157 / 0.177)
+    if (p.cold && p.B > 64 * 256 && kl <= 64 * 1024) {
         // keys in q2 (written again only by the second pass), buckets / cursors / count in the counter block,
         // the order in the last slot of the int workspace
         int* keys = q2; int* seg = counters + 96 + NBIN * BIN_STRIDE;
