@@ -86,6 +86,9 @@ typedef struct mpcqp_solve_opts {
                              1 or 2 alone are for per-kernel timing and reuse the kept (z, w); bits 2 / 3 (with 3) stop
                              after the first active-set pass / after the cold-start ordering kernels: timing only, the
                              batch is left partly solved */
+    int    keep_state;    /* 1 (default): leave the solution in the handle's (z, w) for a later warm start / mpcqp_shift;
+                             0: skip those writes (two thirds of a cold solve's HBM traffic) -- a following warm_start then
+                             starts cold and mpcqp_shift reports that there is no state */
 } mpcqp_solve_opts;
 
 /* all members are device pointers of length batch, each may be NULL */
@@ -144,6 +147,19 @@ int mpcqp_general_rows(mpcqp_handle h, int* m, int* uses_rows_kernel);
  * mpcqp_solve skips the ADMM GEMM kernel and the dual active-set kernel does the whole solve (cold, or from the
  * kept state with warm_start = 1); batch must equal n_models. */
 int mpcqp_set_strides(mpcqp_handle h, long xref_stride, long uref_stride, long bound_stride);
+
+/* Component split.  When the Jacobi-scaled Hessian of a SHARED model (n_models = 1, input box only, N*nu <= 128) is block
+ * diagonal under a permutation of the rows -- models built from independent axes, as the reference's
+ * Launch3DPlanner.py:61-108 builds x, y, z -- every instance is a set of independent box QPs, and a cold mpcqp_solve runs
+ * the dual active-set kernels per block (same minimiser, same outputs; fewer flops per step, shorter dependent chains).
+ * mpcqp_factor looks for the blocks on its synchronous set-up call: entries of Hs and of Hs^-1 at or below `tol` relative
+ * to the unit diagonal count as no coupling (default 1e-14: rounding noise of the assembly; 0 keeps the current value).
+ * enable = 0 switches the search off.  Takes effect with the next mpcqp_factor.  Warm-started solves, ADMM iterations
+ * first, one model per instance and the general-constraint mode do not split. */
+int mpcqp_set_split(mpcqp_handle h, int enable, double tol);
+/* what the last mpcqp_factor found: components (0 = not split), rows per component (the largest, padded to even);
+ * row_map (host, N*nu ints, may be NULL): component of every row */
+int mpcqp_split_info(mpcqp_handle h, int* components, int* rows_per_component, int* row_map, int row_map_len);
 
 /* -- kernels ----------------------------------------------------------------------- */
 /* rollout Gamma/Phi, H = Gamma'Qbar Gamma + Rbar, F = Gamma'Qbar Phi, f0  (fp64 MFMA) */

@@ -27,7 +27,7 @@ class SolveOpts(C.Structure):
     _fields_ = [("max_iter", C.c_int), ("min_iter", C.c_int), ("check_every", C.c_int),
                 ("eps_abs", C.c_double), ("eps_rel", C.c_double), ("alpha", C.c_double),
                 ("polish", C.c_int), ("polish_refine", C.c_int), ("polish_max_steps", C.c_int),
-                ("warm_start", C.c_int), ("stages", C.c_int)]
+                ("warm_start", C.c_int), ("stages", C.c_int), ("keep_state", C.c_int)]
 
 
 class DenseOpts(C.Structure):
@@ -53,6 +53,8 @@ SYMBOLS = [
     ("mpcqp_set_state_constraints", C.c_int, [C.c_void_p] * 6 + [C.c_int]),
     ("mpcqp_set_general_opts", C.c_int, [C.c_void_p, C.c_int, C.c_long]),
     ("mpcqp_general_rows", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    ("mpcqp_set_split", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    ("mpcqp_split_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     ("mpcqp_assemble", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_factor", C.c_int, [C.c_void_p, C.POINTER(FactorOpts), C.c_void_p]),
     ("mpcqp_solve", C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.POINTER(Info),

@@ -91,7 +91,7 @@ void mpcqp_default_solve_opts(mpcqp_solve_opts* o) {
     if (!o) return;
     o->max_iter = 0; o->min_iter = 5; o->check_every = 5;
     o->eps_abs = 1e-6; o->eps_rel = 1e-6; o->alpha = 1.6;
-    o->polish = 1; o->polish_refine = -1; o->polish_max_steps = 0; o->warm_start = 0; o->stages = 3;
+    o->polish = 1; o->polish_refine = -1; o->polish_max_steps = 0; o->warm_start = 0; o->stages = 3; o->keep_state = 1;
 }
 
 int mpcqp_create(mpcqp_handle* out, const mpcqp_dims* dims, int device_id) {
@@ -140,6 +140,7 @@ int mpcqp_destroy(mpcqp_handle h) {
                     h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws, h->hbuf1, h->hbuf2, h->facL, h->facBlk};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     general_free(h);
+    split_free(h);
     delete h;
     return MPCQP_OK;
 }
@@ -194,6 +195,7 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     if (!h->umin) { h->err = "factor: set_constraints first"; return MPCQP_ESTATE; }
     HIPCHK(h, hipSetDevice(h->dev));
     hipStream_t st = static_cast<hipStream_t>(stream);
+    h->sp_C = 0;            // the component split belongs to the factorisation it was found in (split_setup below)
     // state-box / polytopic rows, or more inputs than the box kernels hold: the general-constraint path (general.hip)
     if (h->g_xmin || h->g_C || h->g_path == 2 || !admm_shared_box_supported(h->NT, h->S)) return factor_general(h, st);
     if (h->general) general_free(h);
@@ -215,6 +217,8 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     h->rho = h->dims.n_models > 1 ? 1.0 : r3[0];
     h->inv_resid = r3[3];
     h->factored = true; h->has_state = h->has_state && opts && opts->keep_state;
+    // a shared model whose Hessian is block diagonal under a permutation is solved block by block (split.hip)
+    if (h->dims.n_models == 1) TRY(split_setup(h, st));
     return MPCQP_OK;
 }
 
@@ -247,7 +251,30 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
     const bool skip_admm = o.max_iter == 0 && o.polish && (o.stages & 2);   // polish.hip: no_admm
     if ((o.stages & 1) && h->dims.n_models == 1 && !skip_admm) TRY(launch_admm_shared_box(h, x0, batch, o, st));
     if (o.stages & 2) TRY(launch_polish_box(h, x0, batch, U, info, o, st));
-    h->has_state = true; h->Blast = batch;
+    h->has_state = o.keep_state != 0; h->Blast = batch;
+    return MPCQP_OK;
+}
+
+int mpcqp_set_split(mpcqp_handle h, int enable, double tol) {
+    if (!h) return MPCQP_EINVAL;
+    if (tol < 0.0 || tol > 1e-6) { h->err = "set_split: tol must be in [0, 1e-6] (0 keeps the current value)"; return MPCQP_EINVAL; }
+    h->sp_enable = enable ? 1 : 0;
+    if (tol > 0.0) h->sp_tol = tol;
+    h->factored = false;        // takes effect with the next factorisation
+    return MPCQP_OK;
+}
+
+int mpcqp_split_info(mpcqp_handle h, int* components, int* rows_per_component, int* row_map, int row_map_len) {
+    if (!h) return MPCQP_EINVAL;
+    if (components) *components = h->sp_C;
+    if (rows_per_component) *rows_per_component = h->sp_C ? h->sp_ns : 0;
+    if (row_map) {
+        if (row_map_len < h->n) { h->err = "split_info: row_map needs N*nu entries"; return MPCQP_EINVAL; }
+        if (!h->sp_C) { for (int i = 0; i < h->n; ++i) row_map[i] = 0; return MPCQP_OK; }
+        HIPCHK(h, hipSetDevice(h->dev));
+        HIPCHK(h, hipMemcpy(row_map, h->sp_rowmap, (size_t)h->n * sizeof(int), hipMemcpyDeviceToHost));
+        for (int i = 0; i < h->n; ++i) row_map[i] >>= 16;
+    }
     return MPCQP_OK;
 }
 

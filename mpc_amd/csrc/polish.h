@@ -41,6 +41,14 @@ struct PolParams {
                                    // seg_counts[32 k]; the place p of the order (largest bucket first) is looked up by the reader
     int *qout, *qout_count;        // queue for the instances this pass could not finish (nullptr: none)
     unsigned long long* prof;      // debugging only (POLISH_PROF builds): per-phase cycle sums, else nullptr
+    int keep_state;                // 1: leave the solution in (z, w) for a later warm start / shift; 0: skip those writes
+    // component split (split.hip; SPLIT instantiations of polish_oct_kernel): B counts SUB-instances (instance * sp_C +
+    // component), n is the (uniform, padded) number of rows of a component, and Hi [C][n][n], KuT [C][nx+1][sp_ld], lbs / ubs /
+    // d [C][sp_ld] are packed per component; x0, U, z, w, info stay per instance and in the row order of the whole problem
+    int sp_C, sp_ld, sp_n, sp_NP;  // components (0: not split), row stride of the packed vectors, rows / padded rows of the whole problem
+    const int* sp_perm;            // [C][sp_ld]: component row -> row of the whole problem, -1 = padding
+    double* sp_part; int* sp_steps; int* sp_done;   // per sub-instance: its part of the objective, its steps; per instance: components finished
+    int *sp_failq, *sp_failq_count;                // instances a component of which could not be finished: solved again as a whole
 };
 
 // fast path; returns MPCQP_ENOTIMPL if the shape does not fit it (the caller then uses the wave kernel)
@@ -48,3 +56,7 @@ int launch_polish_quad(const PolParams& p, int* q1, int* q2, int* counters, hipS
 // third chance: a whole wave per instance and up to 64 active rows with the same explicit-inverse kernel (the queue of the
 // second pass in p.qin, what outgrows it into p.qout); -1 if the shape does not fit
 int launch_polish_oct64(const PolParams& p, hipStream_t st);
+// split.hip: the cold solve of a model with independent components; -1 if it does not apply (the caller goes on unsplit)
+int launch_polish_split(mpcqp_handle h, const PolParams& p, hipStream_t st, int stop_after);
+// polish_quad.hip: one pass of the split cascade over p.B sub-instances (or p.qin): slots = 8, 16 or 32
+int launch_oct_split(const PolParams& p, int slots, hipStream_t st);

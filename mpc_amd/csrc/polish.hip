@@ -502,7 +502,7 @@ __device__ void polish_wave(const PolParams& pin, const int inst, WaveLds<KMAX>&
             const double dj = p.d[j];
             p.U[(size_t)inst * n + j] = dj * x[q];
             if (p.info.lam) p.info.lam[(size_t)inst * n + j] = lam[q] / dj;
-            if (status == MPCQP_SOLVED) {       // keep the polished point as warm-start state
+            if (status == MPCQP_SOLVED && p.keep_state) {       // keep the polished point as warm-start state
                 zb[j] = x[q];
                 wb[j] = lam[q] / p.rho;
             }
@@ -548,6 +548,10 @@ int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
 
 }  // namespace
 
+// the any-size kernel over a device-side queue of instances (split.hip: instances a component of which the split cascade
+// could not finish)
+int launch_polish_wave_queue(const PolParams& p, hipStream_t st) { return launch_pol<128, 1>(p, st, 512); }
+
 int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
                       const mpcqp_solve_opts& o, hipStream_t st) {
     PolParams p{};
@@ -562,6 +566,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     // refine < 0: automatic -- one step with Hs itself only if the explicit inverse is not accurate enough
     p.refine = o.polish_refine >= 0 ? o.polish_refine : (h->inv_resid > 1e-9 ? 1 : 0); p.max_steps = o.polish_max_steps > 0 ? o.polish_max_steps : 4 * h->n + 16;
     p.rho = h->rho;
+    p.keep_state = o.keep_state ? 1 : 0;
     p.prof = nullptr;
 #ifdef POLISH_PROF
     static unsigned long long* profbuf = nullptr;
@@ -592,7 +597,11 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     // what those cannot finish is queued in q2 for the wave-per-instance kernel.  Shapes the fast path does not
     // take (refinement requested, polish off, n > 128) run the wave-per-instance kernel on the whole batch.
     // diagnostics for bench.py: stages bit 2 stops after the first pass, bit 3 after the cold-start ordering kernels
-    int rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st, (o.stages & 8) ? 2 : ((o.stages & 4) ? 1 : 0));
+    const int stop_after = (o.stages & 8) ? 2 : ((o.stages & 4) ? 1 : 0);
+    // a model whose Hessian falls into independent blocks: the cold solve runs per block (split.hip); -1 = does not apply
+    int rc = per_model ? -1 : launch_polish_split(h, p, st, stop_after);
+    if (rc == 0) return MPCQP_OK;
+    if (rc < 0) rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st, stop_after);
     if (rc == 0 && (o.stages & 12)) return MPCQP_OK;
 #ifdef POLISH_PROF
     if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {

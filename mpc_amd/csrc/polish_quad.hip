@@ -53,12 +53,12 @@ __device__ __forceinline__ void wsync() {
     __builtin_amdgcn_wave_barrier();
 }
 constexpr int DPP_ROR8 = 0x128;                     // row_ror:8: lane i <-> i+8 of each 16
-// sum over the G (8 or 16) lanes of a group, result in all of them
+// sum over the G (4 .. 64) lanes of a group, result in all of them
 template <int G>
 __device__ __forceinline__ double grp_sum(double v) {
     v += dpp_d<DPP_XOR1>(v);
     v += dpp_d<DPP_XOR2>(v);
-    v += dpp_d<DPP_HMIRROR>(v);
+    if (G >= 8) v += dpp_d<DPP_HMIRROR>(v);
     if (G >= 16) v += dpp_d<DPP_ROR8>(v);
     if (G >= 32) v += __shfl_xor(v, 16);        // across the DPP rows of the group
     if (G == 64) v += __shfl_xor(v, 32);
@@ -72,7 +72,8 @@ __device__ __forceinline__ void min_step(double& t, int& j) {
 // (smallest t, its index; ties to the lower index) over the group
 template <int G>
 __device__ __forceinline__ void grp_min(double& t, int& j) {
-    min_step<DPP_XOR1>(t, j); min_step<DPP_XOR2>(t, j); min_step<DPP_HMIRROR>(t, j);
+    min_step<DPP_XOR1>(t, j); min_step<DPP_XOR2>(t, j);
+    if (G >= 8) min_step<DPP_HMIRROR>(t, j);
     if (G >= 16) min_step<DPP_ROR8>(t, j);
     if (G >= 32) {
         const double ot = __shfl_xor(t, 16); const int oj = __shfl_xor(j, 16);
@@ -87,7 +88,8 @@ template <int CTRL>
 __device__ __forceinline__ void imin_step(int& j) { const int oj = dpp_i<CTRL>(j); j = oj < j ? oj : j; }
 template <int G>
 __device__ __forceinline__ int grp_imin(int j) {
-    imin_step<DPP_XOR1>(j); imin_step<DPP_XOR2>(j); imin_step<DPP_HMIRROR>(j);
+    imin_step<DPP_XOR1>(j); imin_step<DPP_XOR2>(j);
+    if (G >= 8) imin_step<DPP_HMIRROR>(j);
     if (G >= 16) imin_step<DPP_ROR8>(j);
     if (G >= 32) { const int oj = __shfl_xor(j, 16); j = oj < j ? oj : j; }
     if (G == 64) { const int oj = __shfl_xor(j, 32); j = oj < j ? oj : j; }
@@ -100,7 +102,8 @@ __device__ __forceinline__ void max_step(double& v, int& code) {
 }
 template <int G>
 __device__ __forceinline__ void grp_max(double& v, int& code) {
-    max_step<DPP_XOR1>(v, code); max_step<DPP_XOR2>(v, code); max_step<DPP_HMIRROR>(v, code);
+    max_step<DPP_XOR1>(v, code); max_step<DPP_XOR2>(v, code);
+    if (G >= 8) max_step<DPP_HMIRROR>(v, code);
     if (G >= 16) max_step<DPP_ROR8>(v, code);
     if (G >= 32) {
         const double ov = __shfl_xor(v, 16); const int oc = __shfl_xor(code, 16);
@@ -156,17 +159,19 @@ constexpr int BIN_STRIDE = 32;
     constexpr int LD = NQ; \
     constexpr int CH = (G >= 32) ? OCT_CH32 : 4, XCH = (G >= 32) ? OCT_XCH32 : 2; \
     const int n = p.n, nx = p.nx; \
+    [[maybe_unused]] const int CN = SPLIT ? p.sp_C : 1; \
     const int tid = threadIdx.x, g = tid & (G - 1), li = tid / G; \
     [[maybe_unused]] const int lane = tid & 63; \
     const int SW = (G == 8 && !(RP & 1)) ? ((li >> 1) & 1) : 0; \
     [[maybe_unused]] const int rbE = 2 * g + 2 * G * SW, rbO = 2 * g - 2 * G * SW; \
     double* sHi = reinterpret_cast<double*>(smem); \
-    double* sLb = sHi + (size_t)n * LD; \
-    double* sUb = sLb + NQ; \
-    double* sD = sUb + NQ; \
-    double2* sBT = reinterpret_cast<double2*>(sD + NQ); \
-    double* sKu = sD + 3 * NQ; \
-    double* sStage = sKu + (size_t)(nx + 1) * NQ; \
+    double* sLb = sHi + (size_t)CN * n * LD; \
+    double* sUb = sLb + CN * NQ; \
+    double* sD = sUb + CN * NQ; \
+    double2* sBT = reinterpret_cast<double2*>(sD + CN * NQ); \
+    [[maybe_unused]] int* sPerm = reinterpret_cast<int*>(sD + 3 * CN * NQ); \
+    double* sKu = sD + 3 * CN * NQ + (SPLIT ? CN * NQ / 2 : 0); \
+    double* sStage = sKu + (size_t)CN * (nx + 1) * NQ; \
     double* sX0 = sStage; \
     constexpr int KST = KMAX + 4; \
     double* myR = sKu + (size_t)li * KST; \
@@ -175,10 +180,18 @@ constexpr int BIN_STRIDE = 32;
 
 
 // one block of IPW instances: the whole active-set solve
-template <int G, int RP, int KMAX, int THREADS, bool COLD>
+// SPLIT: the work items are SUB-instances (instance `inst`, component `comp`, id `sub` = inst * components + comp) of a model
+// whose Hessian is block diagonal under a permutation (split.hip): every component is a small box QP of its own, with its
+// block of Hi, its rows of the map and its bounds at an offset in LDS; outputs go to the rows of the whole problem through
+// the component's row map, and the last component of an instance to finish adds up the instance's objective and step count.
+template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT>
 __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, const int total, unsigned long long* pacc_out,
-                                          const int inst, const double (&xpre)[64 / G]) {
+                                          const int inst, const double (&xpre)[64 / G], const int sub, const int comp) {
+    static_assert(!SPLIT || COLD, "the component split is a cold-start path");
     OCT_LAYOUT
+    const int hiB = SPLIT ? comp * n * LD : 0;              // my component's block of Hi, its bounds, its rows of the map
+    const int bB = SPLIT ? comp * NQ : 0;
+    const int kuB = SPLIT ? comp * (nx + 1) * NQ : 0;
 #ifdef POLISH_PROF
     unsigned long long pacc[16] = {};
     long long tprof = clock64();
@@ -221,11 +234,11 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
     double c0 = 0.0;
     {
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) x[j] = sKu[nx * NQ + ROWJ(j)];
+        for (int j = 0; j < RPL; ++j) x[j] = sKu[kuB + nx * NQ + ROWJ(j)];
         for (int c = 0; c < nx; ++c) {
             const double xc = sX0[li * nx + c];
 #pragma unroll
-            for (int j = 0; j < RPL; ++j) x[j] += sKu[c * NQ + ROWJ(j)] * xc;
+            for (int j = 0; j < RPL; ++j) x[j] += sKu[kuB + c * NQ + ROWJ(j)] * xc;
         }
         {                   // c0 = [x0;1]' Cq [x0;1], rows a = g, g+G, .. of the form in lane g
             const int nx1 = nx + 1;
@@ -237,6 +250,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             }
         }
         c0 = grp_sum<G>(c0);
+        if (SPLIT && comp != 0) c0 = 0.0;       // the instance's unconstrained part is counted once, by component 0
     }
 
     // ---- active-set guess from the ADMM iterate (z at a bound and the scaled dual pushing outwards) ---
@@ -407,7 +421,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             const bool actt = wact && t < k0;
             if (!__any(actt)) break;
             const int pr = actt ? myA[t] : 0;
-            const int po = pr * LD;
+            const int po = hiB + pr * LD;
             double r[NS], hown[NS];
             sinv_h(po, min(t, k0), r, hown);
             double part = 0.0;
@@ -479,7 +493,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             if (!__any(cb < khi)) break;
             double la[XCH]; int oa[XCH];
 #pragma unroll
-            for (int u = 0; u < XCH; ++u) { la[u] = myR[cb + u]; oa[u] = myA[cb + u] * LD; }
+            for (int u = 0; u < XCH; ++u) { la[u] = myR[cb + u]; oa[u] = hiB + myA[cb + u] * LD; }
 #pragma unroll
             for (int u = 0; u < XCH; ++u)
 #pragma unroll
@@ -507,7 +521,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #pragma unroll
             for (int u = 0; u < CH; ++u)
 #pragma unroll
-                for (int i = 0; i < NS; ++i) e[i] -= sHi[rw[u] * LD + ro[i]] * lv[u];      // Hi is symmetric
+                for (int i = 0; i < NS; ++i) e[i] -= sHi[hiB + rw[u] * LD + ro[i]] * lv[u];      // Hi is symmetric
         }
 #pragma unroll
         for (int i = 0; i < NS; ++i) if (sgO[i] == 0.0) e[i] = 0.0;
@@ -548,7 +562,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
     if (p.hand_in) {
         constexpr int HK = KMAX / 2;                    // the previous pass has half the slots
         constexpr int HENT = HK * HK + 4 * HK + 2;
-        const bool handed = valid && !fail && p.need_big[inst] == 3;
+        const bool handed = valid && !fail && p.need_big[sub] == 3;
         if (__any(handed)) {
             if (handed) {
                 const double* hb = p.hand_in + (size_t)(slot0 + li) * HENT;
@@ -591,7 +605,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {     // violation beyond the tolerance: x - (hi + tol) or (lo - tol) - x
             const int row = ROWJ(j);
-            const double2 bt = sBT[row];
+            const double2 bt = sBT[bB + row];
             const double vu = x[j] - bt.y, vl = bt.x - x[j];
             const double v = fmax(vu, vl);
             if (!((m >> j) & 1u) && v > best) { best = v; code = 2 * row + (vu > vl ? 1 : 0); }
@@ -600,13 +614,13 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         bool has = run && code >= 0;
         PROF_MARK(9);
         if (code >= 0) {                    // the violation itself: add the row's tolerance back
-            const double hi = sUb[code >> 1], lo = sLb[code >> 1];
+            const double hi = sUb[bB + (code >> 1)], lo = sLb[bB + (code >> 1)];
             best += 1e-12 * bound_scale(lo, hi);
         }
         if (!__any(has)) break;
         if (has && ++guard > p.max_steps) { fail = true; why = 5; run = false; has = false; }
         const int pr = has ? (code >> 1) : 0;
-        const int po = pr * LD;
+        const int po = hiB + pr * LD;
         const bool upP = code & 1;
         const double sp = upP ? 1.0 : -1.0;
         const double hpp = sHi[po + pr];
@@ -658,7 +672,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
                 if (!__any(cb < khi)) break;
                 double ca[XCH]; int oa[XCH];
 #pragma unroll
-                for (int u = 0; u < XCH; ++u) { ca[u] = cp * myR[cb + u]; oa[u] = myA[cb + u] * LD; }
+                for (int u = 0; u < XCH; ++u) { ca[u] = cp * myR[cb + u]; oa[u] = hiB + myA[cb + u] * LD; }
 #pragma unroll
                 for (int u = 0; u < XCH; ++u)
 #pragma unroll
@@ -736,15 +750,71 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
     const bool okk = valid && !over && !fail;
     int qslot = -1;
     if (valid && g == 0) {
-        if (!okk && p.qout) { qslot = atomicAdd(p.qout_count, 1); p.qout[qslot] = inst; }      // queue for the next, larger pass
+        if (!okk && p.qout) { qslot = atomicAdd(p.qout_count, 1); p.qout[qslot] = sub; }      // queue for the next, larger pass
         const bool give = over && why == 3 && qslot >= 0 && ((p.hand_out && qslot < p.hand_out_cap) || p.hand_zw);
-        p.need_big[inst] = okk ? 0 : (why == 3 && !give ? 9 : (why ? why : 7));       // 3 = handed over, 9 = list full, start again
+        p.need_big[sub] = okk ? 0 : (why == 3 && !give ? 9 : (why ? why : 7));       // 3 = handed over, 9 = list full, start again
     }
     double dual = 0.0;
 #pragma unroll
     for (int i = 0; i < NS; ++i) dual += lam[i] * rhs[i];
     dual = grp_sum<G>(dual);
     const double obj = 0.5 * c0 + 0.5 * dual;       // f(xu) + 1/2 lam'S lam
+    if constexpr (SPLIT) {
+        if (okk) {          // my component's rows of the instance, through the row map (8-byte stores)
+            double* Ub = p.U + (size_t)inst * p.sp_n;
+            double* lamb = p.info.lam ? p.info.lam + (size_t)inst * p.sp_n : nullptr;
+#pragma unroll
+            for (int j = 0; j < RPL; ++j) {
+                const int row = ROWJ(j);
+                const int gr = sPerm[bB + row];
+                if (gr >= 0) {
+                    const bool act = ((mU | mL) >> j) & 1u;
+                    const double xo = ((mU >> j) & 1u) ? sUb[bB + row] : (((mL >> j) & 1u) ? sLb[bB + row] : x[j]);
+                    Ub[gr] = sD[bB + row] * xo;
+                    if (p.keep_state) { zb[gr] = xo; if (!act) wb[gr] = 0.0; }
+                    if (lamb && !act) lamb[gr] = 0.0;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NS; ++i)
+                if (sgO[i] != 0.0) {
+                    const int row = raO[i];
+                    const int gr = sPerm[bB + row];
+                    if (p.keep_state) wb[gr] = lam[i] / p.rho;
+                    if (lamb) lamb[gr] = lam[i] / sD[bB + row];
+                }
+        }
+        // An instance is done when its last component is: every component leaves its part of the objective and its steps, then
+        // counts itself in; the one that completes the count adds the parts up in component order (so the sum does not depend on
+        // who finishes last) and writes the instance's record.  A component that cannot be finished by the last pass of the
+        // cascade (numerical guard) counts itself in with the high half set: the instance is then queued, once, to be solved
+        // again as a whole, and that kernel writes its record.
+        if (valid && g == 0 && (okk || !p.qout)) {
+            int add = 1;
+            if (okk) { p.sp_part[sub] = obj; p.sp_steps[sub] = steps; __threadfence(); }
+            else add += 1 << 16;
+            const int old = atomicAdd(&p.sp_done[inst], add);
+            const int now = old + add;
+            if (!okk && (old >> 16) == 0) p.sp_failq[atomicAdd(p.sp_failq_count, 1)] = inst;
+            if ((now & 0xFFFF) == CN) {
+                p.sp_done[inst] = 0;            // ready for the next solve
+                if ((now >> 16) == 0) {
+                    __threadfence();
+                    double o = 0.0; int sst = 0;
+                    for (int c = 0; c < CN; ++c) {
+                        o += __hip_atomic_load(p.sp_part + (size_t)inst * CN + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        sst += __hip_atomic_load(p.sp_steps + (size_t)inst * CN + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    if (p.info.status) p.info.status[inst] = MPCQP_SOLVED;
+                    if (p.info.obj) p.info.obj[inst] = o;
+                    if (p.info.iters) p.info.iters[inst] = 0;
+                    if (p.info.prim_res) p.info.prim_res[inst] = 0.0;
+                    if (p.info.dual_res) p.info.dual_res[inst] = 0.0;
+                    if (p.info.polish_steps) p.info.polish_steps[inst] = sst;
+                }
+            }
+        }
+    } else
 #ifdef POLISH_NOOUT
     if (okk && p.B < 0) {
 #else
@@ -760,13 +830,13 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
                     xo.x = ((mU >> (2 * jj)) & 1u) ? sUb[row] : (((mL >> (2 * jj)) & 1u) ? sLb[row] : x[2 * jj]);
                     xo.y = ((mU >> (2 * jj + 1)) & 1u) ? sUb[row + 1] : (((mL >> (2 * jj + 1)) & 1u) ? sLb[row + 1] : x[2 * jj + 1]);
                     *reinterpret_cast<double2*>(p.U + (size_t)inst * n + row) = make_double2(sD[row] * xo.x, sD[row + 1] * xo.y);
-                    *reinterpret_cast<double2*>(zb + row) = xo;          // the polished point is the warm-start state
+                    if (p.keep_state) *reinterpret_cast<double2*>(zb + row) = xo;          // the polished point is the warm-start state
                     if (a2 == 0u) {
-                        *reinterpret_cast<double2*>(wb + row) = make_double2(0.0, 0.0);
+                        if (p.keep_state) *reinterpret_cast<double2*>(wb + row) = make_double2(0.0, 0.0);
                         if (p.info.lam) *reinterpret_cast<double2*>(p.info.lam + (size_t)inst * n + row) = make_double2(0.0, 0.0);
                     } else {
-                        if (!(a2 & 1u)) { wb[row] = 0.0; if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0; }
-                        if (!(a2 & 2u)) { wb[row + 1] = 0.0; if (p.info.lam) p.info.lam[(size_t)inst * n + row + 1] = 0.0; }
+                        if (!(a2 & 1u)) { if (p.keep_state) wb[row] = 0.0; if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0; }
+                        if (!(a2 & 2u)) { if (p.keep_state) wb[row + 1] = 0.0; if (p.info.lam) p.info.lam[(size_t)inst * n + row + 1] = 0.0; }
                     }
                 }
             }
@@ -778,9 +848,9 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
                     const bool act = ((mU | mL) >> j) & 1u;
                     const double xo = ((mU >> j) & 1u) ? sUb[row] : (((mL >> j) & 1u) ? sLb[row] : x[j]);
                     p.U[(size_t)inst * n + row] = sD[row] * xo;
-                    zb[row] = xo;
+                    if (p.keep_state) zb[row] = xo;
                     if (!act) {                 // rows in the active set get their multiplier from the slot owner below
-                        wb[row] = 0.0;
+                        if (p.keep_state) wb[row] = 0.0;
                         if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0;
                     }
                 }
@@ -790,7 +860,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         for (int i = 0; i < NS; ++i)
             if (sgO[i] != 0.0) {
                 const int row = raO[i];
-                wb[row] = lam[i] / p.rho;
+                if (p.keep_state) wb[row] = lam[i] / p.rho;
                 if (p.info.lam) p.info.lam[(size_t)inst * n + row] = lam[i] / sD[row];
             }
         if (g == 0) {
@@ -819,7 +889,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
             if (g == 0) hb[KMAX * KMAX + 4 * KMAX] = (double)steps;
         }
     }
-    if (p.hand_zw && p.qout && valid && over && why == 3) {
+    if (!SPLIT && p.hand_zw && p.qout && valid && over && why == 3) {
 #pragma unroll
         for (int j = 0; j < RPL; ++j) {
             const int row = ROWJ(j);
@@ -838,7 +908,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 
 // COLD: no (z, w) to start from -- the instantiation every default solve uses (it carries neither the iterate registers nor
 // the warm-phase code).
-template <int G, int RP, int KMAX, int THREADS, bool COLD>
+template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT>
 __device__ __forceinline__ void oct_body(const PolParams& p) {
     OCT_LAYOUT
     (void)sLb; (void)sUb; (void)sD; (void)sBT; (void)sX0; (void)myR; (void)myV; (void)myA; (void)g; (void)li; (void)CH; (void)XCH; (void)NS; (void)RPL;
@@ -855,7 +925,7 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
     const int blk = blockIdx.x;
     const int slot0 = blk * IPW;
     const bool valid = slot0 + li < total;
-    int inst = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
+    int sub = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
     if (p.seg) {        // my place in the cold-start order (largest bucket first) -> bucket and offset, from the buckets' sizes
         const int pos = slot0 + li;
         int bk = 0, off = 0, acc = 0;
@@ -865,16 +935,19 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
             if (pos >= acc && pos < acc + c) { bk = k; off = pos - acc; }
             acc += c;
         }
-        inst = valid ? p.seg[(size_t)bk * p.B + off] : 0;
+        sub = valid ? p.seg[(size_t)bk * p.B + off] : 0;
     }
+    const int inst = SPLIT ? sub / CN : sub;
+    const int comp = SPLIT ? sub - inst * CN : 0;
     double xpre[64 / G];
 #pragma unroll
     for (int u = 0; u < 64 / G; ++u) { const int c = g + u * G; xpre[u] = (valid && c < nx) ? p.x0[(size_t)inst * nx + c] : 0.0; }
     // ---- stage the shared data --------------------------------------------------------------
     {   // Hi -> LDS.  The workgroup can do nothing else until this has landed, so the loads are as wide as they can be (16 bytes,
         // contiguous over the workgroup) and all in flight before the first LDS write waits for one
+        const int nrH = CN * n;         // rows of the staged matrix: a split model's blocks of Hi follow each other
         if (!(n & 1)) {
-            const int hn = n >> 1, tot2 = n * hn;           // double2 elements
+            const int hn = n >> 1, tot2 = nrH * hn;         // double2 elements
             constexpr int U = 8;
             for (int base = tid; base < tot2; base += U * THREADS) {
                 double2 v[U]; int off[U];
@@ -893,25 +966,35 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
         } else {
             constexpr int TR = THREADS / 128;
             const int tc = tid & 127, tr = tid >> 7;
-            for (int r0 = tr; r0 < n; r0 += 6 * TR) {
+            for (int r0 = tr; r0 < nrH; r0 += 6 * TR) {
                 double v[6];
 #pragma unroll
-                for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; v[u] = (r < n && tc < n) ? p.Hi[(size_t)r * n + tc] : 0.0; }
+                for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; v[u] = (r < nrH && tc < n) ? p.Hi[(size_t)r * n + tc] : 0.0; }
 #pragma unroll
-                for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; if (r < n && tc < n) sHi[r * LD + tc] = v[u]; }
+                for (int u = 0; u < 6; ++u) { const int r = r0 + TR * u; if (r < nrH && tc < n) sHi[r * LD + tc] = v[u]; }
             }
         }
         const int npad = LD - n;            // zero columns n .. LD-1
-        for (int idx = tid; idx < n * npad; idx += THREADS) { const int r = idx / npad; sHi[r * LD + n + (idx - r * npad)] = 0.0; }
+        for (int idx = tid; idx < nrH * npad; idx += THREADS) { const int r = idx / npad; sHi[r * LD + n + (idx - r * npad)] = 0.0; }
     }
-    for (int j = tid; j < NQ; j += THREADS) {
-        sLb[j] = (j < n) ? p.lbs[j] : -1e300;
-        sUb[j] = (j < n) ? p.ubs[j] : 1e300;
-        sD[j] = (j < n) ? p.d[j] : 0.0;
-        const double lo = (j < n) ? p.lbs[j] : -1e300, hi = (j < n) ? p.ubs[j] : 1e300;
+    for (int jc = tid; jc < CN * NQ; jc += THREADS) {
+        const int c = SPLIT ? jc / NQ : 0, j = jc - c * NQ;
+        const int src = SPLIT ? c * p.sp_ld + j : j;        // packed per component (padding rows carry open bounds already)
+        const double lo = (j < n) ? p.lbs[src] : -1e300, hi = (j < n) ? p.ubs[src] : 1e300;
+        sLb[jc] = lo;
+        sUb[jc] = hi;
+        sD[jc] = (j < n) ? p.d[src] : 0.0;
         const double tol = 1e-12 * bound_scale(lo, hi);
-        sBT[j] = make_double2(lo - tol, hi + tol);
+        sBT[jc] = make_double2(lo - tol, hi + tol);
+        if constexpr (SPLIT) sPerm[jc] = (j < n) ? p.sp_perm[src] : -1;
     }
+    if constexpr (SPLIT) {      // the maps of all components: CN (nx+1) rows of NQ from rows of sp_ld
+        const int rows = CN * (nx + 1);
+        for (int idx = tid; idx < rows * NQ; idx += THREADS) {
+            const int r = idx / NQ, j = idx - r * NQ;
+            sKu[idx] = (j < p.sp_ld) ? p.KuT[(size_t)r * p.sp_ld + j] : 0.0;
+        }
+    } else
     {   // the map [Ku | ku]': (nx+1) rows of NQ, 16-byte loads
         // (NP and NQ are multiples of 16), four in flight per thread
         const int hq = NQ / 2, tot2 = (nx + 1) * hq;
@@ -932,7 +1015,7 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
                 if (off[u] >= 0) *reinterpret_cast<double2*>(sKu + off[u]) = vk[u];
         }
     }
-    oct_block<G, RP, KMAX, THREADS, COLD>(p, blockIdx.x, total, pacc, inst, xpre);
+    oct_block<G, RP, KMAX, THREADS, COLD, SPLIT>(p, blockIdx.x, total, pacc, inst, xpre, sub, comp);
 #ifdef POLISH_PROF
     if (lane == 0 && p.prof) {
         unsigned long long tot = 0;
@@ -942,26 +1025,27 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
 #endif
 }
 
-template <int G, int RP, int KMAX, int THREADS, bool COLD>
+template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT = false>
 __global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
-    oct_body<G, RP, KMAX, THREADS, COLD>(p);
+    oct_body<G, RP, KMAX, THREADS, COLD, SPLIT>(p);
 }
 
-template <int G, int RP, int KMAX, int THREADS, bool COLD>
+template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT = false>
 int launch_oct_c(const PolParams& p, int ninst, hipStream_t st) {
     constexpr int NQ = 2 * G * RP, LD = NQ, IPW = THREADS / G;
     if (!p.Cq) return -1;
+    const size_t CN = SPLIT ? p.sp_C : 1;
     const size_t x0s = (size_t)IPW * p.nx * 8;
     // the exchange arrays of the instances (r, v: doubles, the row list: ints) take the place of the map Ku1 and of x0 once the
     // unconstrained minimiser is formed; KMAX + 4 entries apart, so that the instances of a wave read their (broadcast)
     // entries from different banks -- KMAX apart, every other instance of the wave sat on the same ones
     const size_t xch = (size_t)IPW * (KMAX + 4) * 20;
-    const size_t kux = (size_t)(p.nx + 1) * NQ * 8 + x0s;
-    const size_t lds = ((size_t)p.n * LD + 5 * NQ) * 8 + (kux > xch ? kux : xch);
+    const size_t kux = CN * (p.nx + 1) * NQ * 8 + x0s;
+    const size_t lds = (CN * p.n * LD + 5 * CN * NQ + (SPLIT ? CN * NQ / 2 : 0)) * 8 + (kux > xch ? kux : xch);
     if (lds > 160 * 1024) return -1;
-    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS, COLD>), lds);
+    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS, COLD, SPLIT>), lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS, COLD>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
+    hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS, COLD, SPLIT>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
     return (int)hipGetLastError();
 }
 
@@ -985,6 +1069,25 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 }
 
 }  // namespace
+
+// One pass of the split cascade (split.hip): `slots` = 8 (8 lanes per sub-instance), 16 (8 lanes) or 32 (16 lanes) working-set
+// slots; rows per lane from the component size p.n.  -1 if the shape has no instantiation.
+int launch_oct_split(const PolParams& p, int slots, hipStream_t st) {
+    const int n = p.n;
+    if (slots == 8) {
+        if (n <= 16) return launch_oct_c<8, 1, 8, 512, true, true>(p, p.B, st);
+        if (n <= 32) return launch_oct_c<8, 2, 8, 512, true, true>(p, p.B, st);
+        if (n <= 64) return launch_oct_c<8, 4, 8, 512, true, true>(p, p.B, st);
+    } else if (slots == 16) {
+        if (n <= 16) return launch_oct_c<8, 1, 16, 512, true, true>(p, p.B, st);
+        if (n <= 32) return launch_oct_c<8, 2, 16, 512, true, true>(p, p.B, st);
+        if (n <= 64) return launch_oct_c<8, 4, 16, 512, true, true>(p, p.B, st);
+    } else if (slots == 32) {
+        if (n <= 32) return launch_oct_c<16, 1, 32, 512, true, true>(p, p.B, st);
+        if (n <= 64) return launch_oct_c<16, 2, 32, 512, true, true>(p, p.B, st);
+    }
+    return -1;
+}
 
 // ---- cold start: order the instances by expected work ---------------------------------------------------------------------
 // The lanes of a wave walk their 8 (16) instances in lock-step, so a wave takes as long as its slowest instance.  Without

@@ -1,0 +1,208 @@
+// Component split of the shared-model box QP.
+//
+// The condensed Hessian H = Gamma'Qbar Gamma + Rbar couples two inputs only if the dynamics and the weights do.  Models
+// built from independent axes -- the reference's own planners are: Launch3DPlanner.py:61-108 rolls x, y and z out as three
+// separate double integrators, and the quadrotor hover linearisation of BASELINE.json configs[2] is four chains (thrust /
+// height, roll / y, pitch / x, yaw) -- give an H that is block diagonal under a permutation of the rows, and then
+//      min 1/2 U'HU + q'U,  lb <= U <= ub
+// IS a set of independent box QPs, one per block: the minimiser is the stack of theirs, the objective the sum.  The dual
+// active-set method costs O(rows x active bounds) per step and its steps form a dependent chain, so C components of n/C
+// rows are C times fewer flops per step, C times shorter chains, and a Hi that is C times smaller in LDS.
+//
+// split_setup (after the factorisation of a shared model, on the synchronous set-up call): the coupling graph of the
+// Jacobi-scaled Hessian Hs and of its inverse Hi (entries at or below sp_tol relative to the unit diagonal -- rounding
+// noise of the assembly, 1e-15 on configs[2] against couplings >= 0.25 -- do not count), its connected components on the
+// host (n <= 128: a union-find over 16 k entries), then the per-component blocks of Hi, rows of the map x_unc = Ku [x0;1],
+// bounds and scaling packed on the device.  launch_polish_split runs the cold solve on batch x C SUB-instances with the
+// SPLIT instantiations of polish_oct_kernel (polish_quad.hip): 8 working-set slots -> 16 -> 32, each pass handing its
+// state to the next; a component that cannot be finished that way sends its whole instance to the any-size kernel.
+//
+// Reference counterpart: none as code (cvxopt.solvers.qp sees one dense P, LaunchPlannerQPFormulation.py:173); the
+// structure it exploits is the reference's per-axis prediction matrices.
+#include "polish.h"
+#include <algorithm>
+#include <numeric>
+#include <vector>
+#include <cmath>
+
+int launch_polish_wave_queue(const PolParams& p, hipStream_t st);   // polish.hip: any-size kernel over a queue of instances
+
+namespace {
+
+constexpr int NBIN = 32, BIN_STRIDE = 32;       // as polish_quad.hip (cold-start buckets)
+
+// Hi, the map, the bounds and the scaling of every component, gathered through perm [C][ld] (-1 = padding row)
+__global__ void split_pack_kernel(const double* Hi, const double* KuT, const double* lbs, const double* ubs, const double* d,
+                                  const int* perm, int C, int ns, int ld, int n, int NP, int nx1, double* oHi, double* oKuT,
+                                  double* olb, double* oub, double* od) {
+    const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    for (int idx = gid; idx < C * ns * ns; idx += gsz) {
+        const int c = idx / (ns * ns), r = (idx / ns) % ns, j = idx % ns;
+        const int gr = perm[c * ld + r], gj = perm[c * ld + j];
+        oHi[idx] = (gr >= 0 && gj >= 0) ? Hi[(size_t)gr * n + gj] : 0.0;
+    }
+    for (int idx = gid; idx < C * nx1 * ld; idx += gsz) {
+        const int c = idx / (nx1 * ld), k = (idx / ld) % nx1, j = idx % ld;
+        const int gj = perm[c * ld + j];
+        oKuT[idx] = gj >= 0 ? KuT[(size_t)k * NP + gj] : 0.0;
+    }
+    for (int idx = gid; idx < C * ld; idx += gsz) {
+        const int gj = perm[idx];
+        olb[idx] = gj >= 0 ? lbs[gj] : -1e300;      // padding rows: never violated, never written
+        oub[idx] = gj >= 0 ? ubs[gj] : 1e300;
+        od[idx] = gj >= 0 ? d[gj] : 0.0;
+    }
+}
+
+template <typename T>
+int sp_alloc(mpcqp_handle h, T** p, size_t count) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T)));
+    HIPCHK(h, hipMemset(*p, 0, count * sizeof(T)));
+    return MPCQP_OK;
+}
+
+// int workspace for BC sub-instances of B instances:
+//   need[BC] | queue 1 [BC] | queue 2 [BC] | steps[BC] | done[B] | redo queue [B] | counters (96 + 32 x 32) | buckets [32][BC]
+struct SplitWs { int *need, *q1, *q2, *steps, *done, *failq, *counters, *seg; };
+SplitWs split_ws(mpcqp_handle h) {
+    const size_t BC = h->sp_bcap, B = BC / h->sp_C;
+    SplitWs w;
+    w.need = h->sp_iws; w.q1 = w.need + BC; w.q2 = w.q1 + BC; w.steps = w.q2 + BC; w.done = w.steps + BC;
+    w.failq = w.done + B; w.counters = w.failq + B; w.seg = w.counters + 96 + NBIN * BIN_STRIDE;
+    return w;
+}
+
+int split_ensure_batch(mpcqp_handle h, int B) {
+    const int need = ceil_div(B, 64) * 64 * h->sp_C;
+    if (need <= h->sp_bcap) return MPCQP_OK;
+    const size_t BC = need, Bi = BC / h->sp_C;
+    int rc = sp_alloc(h, &h->sp_iws, 4 * BC + 2 * Bi + 96 + NBIN * BIN_STRIDE + (size_t)NBIN * BC);
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_part, BC);
+    // hand-over records (polish_quad.hip): K*K + 4K + 2 doubles for K slots; sized for half (a quarter) of the sub-instances
+    // outgrowing 8 (16) slots -- beyond that a sub-instance starts its next pass from the empty set
+    h->sp_cap1 = (int)(BC / 2); h->sp_cap2 = (int)(BC / 4);
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_hb1, (size_t)h->sp_cap1 * (8 * 8 + 4 * 8 + 2));
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_hb2, (size_t)h->sp_cap2 * (16 * 16 + 4 * 16 + 2));
+    if (rc != MPCQP_OK) { h->sp_bcap = 0; return rc; }
+    h->sp_bcap = need;
+    return MPCQP_OK;
+}
+
+}  // namespace
+
+void split_free(mpcqp_handle h) {
+    void* ptrs[] = {h->sp_perm, h->sp_rowmap, h->sp_Hi, h->sp_KuT, h->sp_lbs, h->sp_ubs, h->sp_d, h->sp_iws, h->sp_part, h->sp_hb1, h->sp_hb2};
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    h->sp_perm = h->sp_rowmap = h->sp_iws = nullptr;
+    h->sp_Hi = h->sp_KuT = h->sp_lbs = h->sp_ubs = h->sp_d = h->sp_part = h->sp_hb1 = h->sp_hb2 = nullptr;
+    h->sp_C = h->sp_ns = h->sp_ld = h->sp_bcap = 0;
+}
+
+int split_setup(mpcqp_handle h, hipStream_t st) {
+    const int n = h->n, nx1 = h->dims.nx + 1;
+    h->sp_C = 0;
+    if (!h->sp_enable || h->dims.n_models != 1 || n < 4 || n > 128) return MPCQP_OK;
+    std::vector<double> Hs((size_t)n * n), Hi((size_t)n * n);
+    HIPCHK(h, hipMemcpyAsync(Hs.data(), h->Hs, Hs.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipMemcpyAsync(Hi.data(), h->Hi, Hi.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    // connected components of the coupling graph (Hs has a unit diagonal; Hi is compared with its own diagonal)
+    std::vector<int> parent(n);
+    std::iota(parent.begin(), parent.end(), 0);
+    auto find = [&](int a) { while (parent[a] != a) { parent[a] = parent[parent[a]]; a = parent[a]; } return a; };
+    const double tol = h->sp_tol;
+    for (int i = 0; i < n; ++i)
+        for (int j = i + 1; j < n; ++j) {
+            const double a = std::fabs(Hs[(size_t)i * n + j]), b = std::fabs(Hs[(size_t)j * n + i]);
+            const double s = std::sqrt(std::fabs(Hi[(size_t)i * n + i] * Hi[(size_t)j * n + j]));
+            const double c = std::fabs(Hi[(size_t)i * n + j]), e = std::fabs(Hi[(size_t)j * n + i]);
+            const bool coupled = !(a <= tol) || !(b <= tol) || !(c <= tol * s) || !(e <= tol * s);   // NaN counts as coupled
+            if (coupled) { const int ri = find(i), rj = find(j); if (ri != rj) parent[std::max(ri, rj)] = std::min(ri, rj); }
+        }
+    std::vector<int> comp_of(n, -1), size;
+    int C = 0;
+    for (int i = 0; i < n; ++i) {               // components numbered by their first row
+        const int r = find(i);
+        if (comp_of[r] < 0) { comp_of[r] = C++; size.push_back(0); }
+        comp_of[i] = comp_of[r];
+        ++size[comp_of[i]];
+    }
+    if (C < 2 || C > 32) return MPCQP_OK;
+    int ns = *std::max_element(size.begin(), size.end());
+    ns += ns & 1;                               // even: 16-byte rows in the staging loops
+    if (ns > 64) return MPCQP_OK;               // what the SPLIT instantiations hold (polish_quad.hip: launch_oct_split)
+    const int ld = 16 * ceil_div(ns, 16);
+    {   // LDS of the widest pass must fit (the formula of launch_oct_c): otherwise the split is not worth having
+        const size_t NQ = ns <= 16 ? 16 : (ns <= 32 ? 32 : 64);
+        const size_t kux = (size_t)C * nx1 * NQ * 8 + 64 * (size_t)h->dims.nx * 8, xch = 64 * 36 * 20;
+        const size_t lds = ((size_t)C * ns * NQ + 5 * C * NQ + C * NQ / 2) * 8 + std::max(kux, xch);
+        if (lds > 150 * 1024) return MPCQP_OK;
+    }
+    std::vector<int> perm((size_t)C * ld, -1), rowmap(h->NP, -1), fill(C, 0);
+    for (int i = 0; i < n; ++i) {
+        const int c = comp_of[i], l = fill[c]++;
+        perm[(size_t)c * ld + l] = i;
+        rowmap[i] = (c << 16) | l;
+    }
+    if (h->sp_perm) { (void)hipFree(h->sp_perm); h->sp_perm = nullptr; }
+    if (h->sp_rowmap) { (void)hipFree(h->sp_rowmap); h->sp_rowmap = nullptr; }
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->sp_perm), perm.size() * sizeof(int)));
+    HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->sp_rowmap), rowmap.size() * sizeof(int)));
+    HIPCHK(h, hipMemcpy(h->sp_perm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(h->sp_rowmap, rowmap.data(), rowmap.size() * sizeof(int), hipMemcpyHostToDevice));
+    int rc = sp_alloc(h, &h->sp_Hi, (size_t)C * ns * ns);
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_KuT, (size_t)C * nx1 * ld);
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_lbs, (size_t)C * ld);
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_ubs, (size_t)C * ld);
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_d, (size_t)C * ld);
+    if (rc != MPCQP_OK) return rc;
+    hipLaunchKernelGGL(split_pack_kernel, dim3(64), dim3(256), 0, st, h->Hi, h->KuT, h->lbs, h->ubs, h->d, h->sp_perm, C, ns,
+                       ld, n, h->NP, nx1, h->sp_Hi, h->sp_KuT, h->sp_lbs, h->sp_ubs, h->sp_d);
+    HIPCHK(h, hipGetLastError());
+    if (h->sp_bcap && (h->sp_bcap % C != 0 || C != h->sp_C)) h->sp_bcap = 0;      // workspace of another component count: size it again
+    h->sp_C = C; h->sp_ns = ns; h->sp_ld = ld;
+    return MPCQP_OK;
+}
+
+int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, int stop_after) {
+    if (h->sp_C < 2 || !pin.cold || !pin.polish || pin.refine > 0 || pin.st_nn || !pin.Cq) return -1;
+    const int C = h->sp_C, Binst = pin.B;
+    if ((long)Binst * C > (1L << 30)) return -1;
+    if (h->sp_bcap && h->sp_bcap % C != 0) h->sp_bcap = 0;
+    int rc = split_ensure_batch(h, Binst);
+    if (rc != MPCQP_OK) return (int)hipErrorOutOfMemory;
+    const SplitWs w = split_ws(h);
+    hipError_t e = hipMemsetAsync(w.counters, 0, (96 + NBIN * BIN_STRIDE) * sizeof(int), st);
+    if (e != hipSuccess) return (int)e;
+    PolParams p = pin;
+    p.sp_C = C; p.sp_ld = h->sp_ld; p.sp_n = pin.n; p.sp_NP = pin.NP; p.sp_perm = h->sp_perm;
+    p.sp_part = h->sp_part; p.sp_steps = w.steps; p.sp_done = w.done; p.sp_failq = w.failq; p.sp_failq_count = w.counters + 2;
+    p.Hi = h->sp_Hi; p.KuT = h->sp_KuT; p.lbs = h->sp_lbs; p.ubs = h->sp_ubs; p.d = h->sp_d;
+    p.n = h->sp_ns; p.B = Binst * C;
+    p.need_big = w.need;
+    p.seg = nullptr; p.seg_counts = nullptr; p.q_gate = 0; p.hand_zw = 0;
+    // 8 slots -> 16 -> 32, each pass taking the queue (and the working states) the one before left
+    PolParams a = p;
+    a.qin = nullptr; a.qin_count = nullptr; a.qout = w.q1; a.qout_count = w.counters;
+    a.hand_in = nullptr; a.hand_out = h->sp_hb1; a.hand_out_cap = h->sp_cap1;
+    rc = launch_oct_split(a, 8, st);
+    if (rc != 0) return rc;
+    if (stop_after == 1) return 0;
+    PolParams b = p;
+    b.qin = w.q1; b.qin_count = w.counters; b.qout = w.q2; b.qout_count = w.counters + 1;
+    b.hand_in = h->sp_hb1; b.hand_out = h->sp_hb2; b.hand_out_cap = h->sp_cap2;
+    rc = launch_oct_split(b, 16, st);
+    if (rc != 0) return rc;
+    PolParams c = p;
+    c.qin = w.q2; c.qin_count = w.counters + 1; c.qout = nullptr; c.qout_count = nullptr;
+    c.hand_in = h->sp_hb2; c.hand_out = nullptr; c.hand_out_cap = 0;
+    rc = launch_oct_split(c, 32, st);
+    if (rc != 0) return rc;
+    // instances with a component the cascade could not finish (more than 32 active rows in a component of more than 32 rows, or
+    // a numerical guard): the whole instance again, unsplit, from the empty set, by the any-size kernel
+    PolParams f = pin;
+    f.pass = 1; f.qin = w.failq; f.qin_count = w.counters + 2; f.qout = nullptr; f.qout_count = nullptr;
+    f.hand_in = nullptr; f.hand_out = nullptr; f.hand_zw = 0; f.seg = nullptr;
+    return launch_polish_wave_queue(f, st);
+}

@@ -65,6 +65,7 @@ class Planner:
         self._general_path = "rows"  # "rows": Gram / constraint-space kernel; "dense": the general dense kernel
         self._rows_mem_limit = 32 << 30  # bytes of shared workspace (Gram matrix) above which "rows" falls back to "dense"
         self._gen_m, self._gen_kernel = 0, None     # rows and kernel of the general-constraint mode, set by setup()
+        self._split = (True, 0.0)    # component split of a shared model (mpcqp_set_split): (enabled, coupling tolerance; 0 = default)
         self.no_sync = False         # True: set-up calls never wait for the device (closed loops)
         self.check_inputs = True     # False: skip the host-side sanity checks that synchronise (u_min <= u_max)
         self.opts = _lib.SolveOpts()
@@ -80,6 +81,23 @@ class Planner:
         if v not in ("rows", "dense"):
             raise ValueError("general_path must be 'rows' or 'dense'")
         self._general_path, self._dirty = v, True
+
+    # component split: a shared model whose Hessian is block diagonal under a permutation (independent axes, as the
+    # reference's Launch3DPlanner.py:61-108 builds x, y, z) is solved block by block; False switches the search off
+    @property
+    def split(self):
+        return self._split[0]
+
+    @split.setter
+    def split(self, v):
+        self._split, self._dirty = (bool(v), self._split[1]), True
+
+    def split_info(self):
+        """After setup(): {'components': C (0 = not split), 'rows': rows per component, 'row_map': component of every row}."""
+        c, r = C.c_int(0), C.c_int(0)
+        rm = (C.c_int * self.n)()
+        self._check(self._lib.mpcqp_split_info(self._h, C.byref(c), C.byref(r), rm, self.n))
+        return {"components": c.value, "rows": r.value, "row_map": list(rm)}
 
     @property
     def rows_mem_limit(self):
@@ -270,6 +288,7 @@ class Planner:
         the factor call does not wait for the device: a failed factorisation then shows up as per-instance status."""
         if self._h is None or "Q" not in self._keep or "u_min" not in self._keep:
             raise RuntimeError("set_model, set_cost and set_constraints must be called before solve")
+        self._check(self._lib.mpcqp_set_split(self._h, int(self._split[0]), float(self._split[1])))
         self._check(self._lib.mpcqp_assemble(self._h, self._stream()))
         # state-box / polytopic rows (or N*nu > 128) are routed inside the library: mpcqp_factor builds the condensed rows on the
         # device and sets up the constraint-space or the dense kernel (general.hip)
