@@ -67,13 +67,14 @@ struct mpcqp_handle_s {
     int *g_iws = nullptr, *g_st = nullptr, *g_it = nullptr, *g_diws = nullptr;
     // component split (split.hip): the scaled Hessian of the shared model is block diagonal under a permutation, so every
     // instance is sp_C independent box QPs; the cold active-set solve then runs on batch * sp_C sub-instances of sp_ns rows
-    int sp_C = 0, sp_ns = 0, sp_ld = 0;     // components (0 = no split), rows per component (uniform, padded, even), 16 ceil(ns / 16)
+    int sp_C = 0, sp_ns = 0, sp_ld = 0;     // components (0 = no split), rows per component (uniform, padded, even), row stride of the packed arrays (16 | 32 | 64)
     int sp_enable = 1;                      // mpcqp_set_split: 0 = never split
     double sp_tol = 1e-14;                  // |Hs_ij|, |Hi_ij| (unit-diagonal scaling) at or below this count as no coupling
     int* sp_perm = nullptr;                 // [C][ld]: component row -> row of the whole problem, -1 = padding
     int* sp_rowmap = nullptr;               // [NP]: row of the whole problem -> component << 16 | component row
     double *sp_Hi = nullptr, *sp_KuT = nullptr, *sp_lbs = nullptr, *sp_ubs = nullptr, *sp_d = nullptr;   // packed per component
-    int sp_bcap = 0;                        // sub-instance capacity of the workspace below (grow only)
+    double* sp_img = nullptr;               // the same as ONE image in the layout of the active-set kernels' LDS (rows of sp_ld)
+    int sp_bcap = 0, sp_wsC = 0, sp_wsld = 0;   // sub-instance capacity of the workspace below (grow only) and the split it was sized for
     int* sp_iws = nullptr; double* sp_part = nullptr;           // int / double workspace of the split solve (split.hip)
     double *sp_hb1 = nullptr, *sp_hb2 = nullptr; int sp_cap1 = 0, sp_cap2 = 0;   // hand-over records 8 -> 16 and 16 -> 32 slots
     bool assembled = false, factored = false, has_state = false;

@@ -43,12 +43,13 @@ struct PolParams {
     unsigned long long* prof;      // debugging only (POLISH_PROF builds): per-phase cycle sums, else nullptr
     int keep_state;                // 1: leave the solution in (z, w) for a later warm start / shift; 0: skip those writes
     // component split (split.hip; SPLIT instantiations of polish_oct_kernel): B counts SUB-instances (instance * sp_C +
-    // component), n is the (uniform, padded) number of rows of a component, and Hi [C][n][n], KuT [C][nx+1][sp_ld], lbs / ubs /
+    // component), n is the (uniform, padded) number of rows of a component, and Hi [C][n][sp_ld], KuT [C][nx+1][sp_ld], lbs / ubs /
     // d [C][sp_ld] are packed per component; x0, U, z, w, info stay per instance and in the row order of the whole problem
     int sp_C, sp_ld, sp_n, sp_NP;  // components (0: not split), row stride of the packed vectors, rows / padded rows of the whole problem
     const int* sp_perm;            // [C][sp_ld]: component row -> row of the whole problem, -1 = padding
-    double* sp_part; int* sp_steps; int* sp_done;   // per sub-instance: its part of the objective, its steps; per instance: components finished
-    int *sp_failq, *sp_failq_count;                // instances a component of which could not be finished: solved again as a whole
+    const double* sp_img;          // all of it (Hi | lbs | ubs | d | bounds -+ tolerance | perm | KuT) laid out as the kernels' LDS for rows of sp_ld
+    double* sp_part; int* sp_steps;                // per sub-instance: its part of the objective, its steps
+    int seg_lo, seg_hi;            // split: the buckets (keys) a launch over the cold-start order takes
 };
 
 // fast path; returns MPCQP_ENOTIMPL if the shape does not fit it (the caller then uses the wave kernel)
@@ -60,3 +61,5 @@ int launch_polish_oct64(const PolParams& p, hipStream_t st);
 int launch_polish_split(mpcqp_handle h, const PolParams& p, hipStream_t st, int stop_after);
 // polish_quad.hip: one pass of the split cascade over p.B sub-instances (or p.qin): slots = 8, 16 or 32
 int launch_oct_split(const PolParams& p, int slots, hipStream_t st);
+// polish_quad.hip: x_unc for every instance, the components it solves written out, the others bucketed by expected work
+int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, hipStream_t st);

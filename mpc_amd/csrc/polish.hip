@@ -548,9 +548,70 @@ int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
 
 }  // namespace
 
-// the any-size kernel over a device-side queue of instances (split.hip: instances a component of which the split cascade
-// could not finish)
-int launch_polish_wave_queue(const PolParams& p, hipStream_t st) { return launch_pol<128, 1>(p, st, 512); }
+// After the passes of a component-split solve (split.hip): one lane per instance adds up its components' parts of the objective
+// and their step counts, in component order, and writes the instance's record; an instance with a component the split
+// cascade could not finish (need != 0: more active rows than the last pass holds, or a numerical guard) is queued and
+// solved again as a whole, from the empty set, by the any-size kernel -- p is the UNSPLIT parameter set plus sp_C / sp_part /
+// sp_steps.
+__global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const int* need, int* redo, int* redo_count) {
+    const int inst = blockIdx.x * 256 + threadIdx.x, C = p.sp_C;
+    if (inst >= p.B) return;
+    const int nx = p.nx, nx1 = nx + 1;
+    const double* xi = p.x0 + (size_t)inst * nx;
+    // every load of the lane first (they are independent; one after the other each is a trip to HBM)
+    constexpr int XM = 16, CM = 8;
+    double xv[XM], pv[CM]; int nv[CM], sv[CM];
+#pragma unroll
+    for (int b = 0; b < XM; ++b) xv[b] = b < nx ? xi[b] : 0.0;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) {
+        const bool in = c < C;
+        nv[c] = in ? need[(size_t)inst * C + c] : 0;
+        pv[c] = in ? p.sp_part[(size_t)inst * C + c] : 0.0;
+        sv[c] = in ? p.sp_steps[(size_t)inst * C + c] : 0;
+    }
+    // the unconstrained part of the objective, 1/2 qs'x_unc = 1/2 [x0;1]' Cq [x0;1], once per instance
+    double o = 0.0;
+    if (nx <= XM) {
+        for (int a = 0; a < nx1; ++a) {
+            const double* cr = p.Cq + (size_t)a * nx1;
+            double sa = cr[nx];
+#pragma unroll
+            for (int b = 0; b < XM; ++b) if (b < nx) sa += cr[b] * xv[b];
+            double va = 1.0;
+#pragma unroll
+            for (int b = 0; b < XM; ++b) if (b == a) va = xv[b];
+            o += sa * va;
+        }
+    } else {
+        for (int a = 0; a < nx1; ++a) {
+            const double* cr = p.Cq + (size_t)a * nx1;
+            double sa = cr[nx];
+            for (int b = 0; b < nx; ++b) sa += cr[b] * xi[b];
+            o += sa * (a < nx ? xi[a] : 1.0);
+        }
+    }
+    o *= 0.5;
+    bool ok = true; int steps = 0;
+#pragma unroll
+    for (int c = 0; c < CM; ++c) { ok = ok && nv[c] == 0; o += pv[c]; steps += sv[c]; }
+    if (!ok) { redo[atomicAdd(redo_count, 1)] = inst; return; }
+    if (p.info.status) p.info.status[inst] = MPCQP_SOLVED;
+    if (p.info.obj) p.info.obj[inst] = o;
+    if (p.info.iters) p.info.iters[inst] = 0;
+    if (p.info.prim_res) p.info.prim_res[inst] = 0.0;
+    if (p.info.dual_res) p.info.dual_res[inst] = 0.0;
+    if (p.info.polish_steps) p.info.polish_steps[inst] = steps;
+}
+
+int launch_split_finish(const PolParams& pin, const int* need, int* redo, int* redo_count, hipStream_t st) {
+    hipLaunchKernelGGL(split_finish_kernel, dim3(ceil_div(pin.B, 256)), dim3(256), 0, st, pin, need, redo, redo_count);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    PolParams p = pin;
+    p.qin = redo; p.qin_count = redo_count;
+    return launch_pol<128, 1>(p, st, 64);       // a short grid: the queue is empty unless a component hit a numerical guard
+}
 
 int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,
                       const mpcqp_solve_opts& o, hipStream_t st) {
@@ -600,6 +661,20 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     const int stop_after = (o.stages & 8) ? 2 : ((o.stages & 4) ? 1 : 0);
     // a model whose Hessian falls into independent blocks: the cold solve runs per block (split.hip); -1 = does not apply
     int rc = per_model ? -1 : launch_polish_split(h, p, st, stop_after);
+#ifdef POLISH_PROF
+    if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {
+        unsigned long long pr[32];
+        (void)hipStreamSynchronize(st);
+        (void)hipMemcpy(pr, profbuf, sizeof(pr), hipMemcpyDeviceToHost);
+        const char* nm[16] = {"stage", "xu", "warm-build", "warm-lam", "xeval", "refine", "out", "#build", "#inner", "scan", "direction",
+                              "x-update", "append", "drop", "#drops", ""};
+        for (int k = 0; k < 2; ++k) {
+            fprintf(stderr, "[split prof] %s-lane passes, cycle sums over all waves:", k ? "16" : "8");
+            for (int i = 0; i < 15; ++i) fprintf(stderr, " %s %llu", nm[i], pr[16 * k + i]);
+            fprintf(stderr, " | longest wave %llu cycles\n", pr[16 * k + 15]);
+        }
+    }
+#endif
     if (rc == 0) return MPCQP_OK;
     if (rc < 0) rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st, stop_after);
     if (rc == 0 && (o.stages & 12)) return MPCQP_OK;

@@ -185,7 +185,7 @@ constexpr int BIN_STRIDE = 32;
 // block of Hi, its rows of the map and its bounds at an offset in LDS; outputs go to the rows of the whole problem through
 // the component's row map, and the last component of an instance to finish adds up the instance's objective and step count.
 template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT>
-__device__ __forceinline__ void oct_block(const PolParams& p, const int blk, const int total, unsigned long long* pacc_out,
+__device__ __forceinline__ void oct_block(const PolParams& p, const int slot, const int total, unsigned long long* pacc_out,
                                           const int inst, const double (&xpre)[64 / G], const int sub, const int comp) {
     static_assert(!SPLIT || COLD, "the component split is a cold-start path");
     OCT_LAYOUT
@@ -196,8 +196,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
     unsigned long long pacc[16] = {};
     long long tprof = clock64();
 #endif
-    const int slot0 = blk * IPW;
-    const bool valid = slot0 + li < total;
+    const bool valid = slot < total;       // slot: my place in the batch / the queue / the cold-start order
     // the ADMM iterate (z, w) of my rows: issued first so that the HBM latency hides behind the staging below
     double zz[RPL], ww[RPL];
 #pragma unroll
@@ -240,7 +239,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
 #pragma unroll
             for (int j = 0; j < RPL; ++j) x[j] += sKu[kuB + c * NQ + ROWJ(j)] * xc;
         }
-        {                   // c0 = [x0;1]' Cq [x0;1], rows a = g, g+G, .. of the form in lane g
+        if constexpr (!SPLIT) {     // c0 = [x0;1]' Cq [x0;1], rows a = g, g+G, .. of the form in lane g (split: split_finish_kernel adds it)
             const int nx1 = nx + 1;
             for (int a = g; a < nx1; a += G) {
                 const double* cr = p.Cq + (size_t)a * nx1;
@@ -249,8 +248,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
                 c0 += sa * (a < nx ? sX0[li * nx + a] : 1.0);
             }
         }
-        c0 = grp_sum<G>(c0);
-        if (SPLIT && comp != 0) c0 = 0.0;       // the instance's unconstrained part is counted once, by component 0
+        if constexpr (!SPLIT) c0 = grp_sum<G>(c0);
     }
 
     // ---- active-set guess from the ADMM iterate (z at a bound and the scaled dual pushing outwards) ---
@@ -565,7 +563,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
         const bool handed = valid && !fail && p.need_big[sub] == 3;
         if (__any(handed)) {
             if (handed) {
-                const double* hb = p.hand_in + (size_t)(slot0 + li) * HENT;
+                const double* hb = p.hand_in + (size_t)slot * HENT;
 #pragma unroll
                 for (int i = 0; i < NS; ++i) {
                     const int a = G * i + g;
@@ -784,36 +782,9 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int blk, con
                     if (lamb) lamb[gr] = lam[i] / sD[bB + row];
                 }
         }
-        // An instance is done when its last component is: every component leaves its part of the objective and its steps, then
-        // counts itself in; the one that completes the count adds the parts up in component order (so the sum does not depend on
-        // who finishes last) and writes the instance's record.  A component that cannot be finished by the last pass of the
-        // cascade (numerical guard) counts itself in with the high half set: the instance is then queued, once, to be solved
-        // again as a whole, and that kernel writes its record.
-        if (valid && g == 0 && (okk || !p.qout)) {
-            int add = 1;
-            if (okk) { p.sp_part[sub] = obj; p.sp_steps[sub] = steps; __threadfence(); }
-            else add += 1 << 16;
-            const int old = atomicAdd(&p.sp_done[inst], add);
-            const int now = old + add;
-            if (!okk && (old >> 16) == 0) p.sp_failq[atomicAdd(p.sp_failq_count, 1)] = inst;
-            if ((now & 0xFFFF) == CN) {
-                p.sp_done[inst] = 0;            // ready for the next solve
-                if ((now >> 16) == 0) {
-                    __threadfence();
-                    double o = 0.0; int sst = 0;
-                    for (int c = 0; c < CN; ++c) {
-                        o += __hip_atomic_load(p.sp_part + (size_t)inst * CN + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        sst += __hip_atomic_load(p.sp_steps + (size_t)inst * CN + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    if (p.info.status) p.info.status[inst] = MPCQP_SOLVED;
-                    if (p.info.obj) p.info.obj[inst] = o;
-                    if (p.info.iters) p.info.iters[inst] = 0;
-                    if (p.info.prim_res) p.info.prim_res[inst] = 0.0;
-                    if (p.info.dual_res) p.info.dual_res[inst] = 0.0;
-                    if (p.info.polish_steps) p.info.polish_steps[inst] = sst;
-                }
-            }
-        }
+        // the instance's record is put together from its components' parts by split_finish_kernel (polish.hip), in component
+        // order, after the last pass: no cross-workgroup hand-shake here (device-scope fences cost an L2 write-back each)
+        if (valid && g == 0 && okk) { p.sp_part[sub] = obj; p.sp_steps[sub] = steps; }
     } else
 #ifdef POLISH_NOOUT
     if (okk && p.B < 0) {
@@ -917,6 +888,7 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
     // over a queue are sized for the whole batch, so most of their workgroups leave here).
     // Persistent workgroups that stage once and walk several blocks were measured twice (round 1 with prefetch, round 2 as
     // a plain loop): the loop around this much code costs 30 % in register allocation, more than the staging it saves.
+    static_assert(!SPLIT, "split models: oct_body_split");
     const int total = p.qin ? *p.qin_count : p.B;
     if ((int)blockIdx.x * IPW >= total) return;
     if ((p.q_gate > 0 && total < p.q_gate) || (p.q_gate < 0 && total >= -p.q_gate)) return;     // not this instantiation's regime
@@ -937,15 +909,14 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
         }
         sub = valid ? p.seg[(size_t)bk * p.B + off] : 0;
     }
-    const int inst = SPLIT ? sub / CN : sub;
-    const int comp = SPLIT ? sub - inst * CN : 0;
+    const int inst = sub, comp = 0;
     double xpre[64 / G];
 #pragma unroll
     for (int u = 0; u < 64 / G; ++u) { const int c = g + u * G; xpre[u] = (valid && c < nx) ? p.x0[(size_t)inst * nx + c] : 0.0; }
     // ---- stage the shared data --------------------------------------------------------------
     {   // Hi -> LDS.  The workgroup can do nothing else until this has landed, so the loads are as wide as they can be (16 bytes,
         // contiguous over the workgroup) and all in flight before the first LDS write waits for one
-        const int nrH = CN * n;         // rows of the staged matrix: a split model's blocks of Hi follow each other
+        const int nrH = n;
         if (!(n & 1)) {
             const int hn = n >> 1, tot2 = nrH * hn;         // double2 elements
             constexpr int U = 8;
@@ -977,24 +948,14 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
         const int npad = LD - n;            // zero columns n .. LD-1
         for (int idx = tid; idx < nrH * npad; idx += THREADS) { const int r = idx / npad; sHi[r * LD + n + (idx - r * npad)] = 0.0; }
     }
-    for (int jc = tid; jc < CN * NQ; jc += THREADS) {
-        const int c = SPLIT ? jc / NQ : 0, j = jc - c * NQ;
-        const int src = SPLIT ? c * p.sp_ld + j : j;        // packed per component (padding rows carry open bounds already)
-        const double lo = (j < n) ? p.lbs[src] : -1e300, hi = (j < n) ? p.ubs[src] : 1e300;
-        sLb[jc] = lo;
-        sUb[jc] = hi;
-        sD[jc] = (j < n) ? p.d[src] : 0.0;
+    for (int j = tid; j < NQ; j += THREADS) {
+        const double lo = (j < n) ? p.lbs[j] : -1e300, hi = (j < n) ? p.ubs[j] : 1e300;
+        sLb[j] = lo;
+        sUb[j] = hi;
+        sD[j] = (j < n) ? p.d[j] : 0.0;
         const double tol = 1e-12 * bound_scale(lo, hi);
-        sBT[jc] = make_double2(lo - tol, hi + tol);
-        if constexpr (SPLIT) sPerm[jc] = (j < n) ? p.sp_perm[src] : -1;
+        sBT[j] = make_double2(lo - tol, hi + tol);
     }
-    if constexpr (SPLIT) {      // the maps of all components: CN (nx+1) rows of NQ from rows of sp_ld
-        const int rows = CN * (nx + 1);
-        for (int idx = tid; idx < rows * NQ; idx += THREADS) {
-            const int r = idx / NQ, j = idx - r * NQ;
-            sKu[idx] = (j < p.sp_ld) ? p.KuT[(size_t)r * p.sp_ld + j] : 0.0;
-        }
-    } else
     {   // the map [Ku | ku]': (nx+1) rows of NQ, 16-byte loads
         // (NP and NQ are multiples of 16), four in flight per thread
         const int hq = NQ / 2, tot2 = (nx + 1) * hq;
@@ -1015,7 +976,7 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
                 if (off[u] >= 0) *reinterpret_cast<double2*>(sKu + off[u]) = vk[u];
         }
     }
-    oct_block<G, RP, KMAX, THREADS, COLD, SPLIT>(p, blockIdx.x, total, pacc, inst, xpre, sub, comp);
+    oct_block<G, RP, KMAX, THREADS, COLD, SPLIT>(p, slot0 + li, total, pacc, inst, xpre, sub, comp);
 #ifdef POLISH_PROF
     if (lane == 0 && p.prof) {
         unsigned long long tot = 0;
@@ -1025,12 +986,88 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
 #endif
 }
 
-template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT = false>
-__global__ __launch_bounds__(THREADS) void polish_oct_kernel(PolParams p) {
-    oct_body<G, RP, KMAX, THREADS, COLD, SPLIT>(p);
+// Component-split models (split.hip): the work items are sub-instances (instance, component), a few hundred flops each, so
+// what a workgroup costs is its start: everything it stages is ONE image in the layout of this LDS (split_setup builds it
+// for LD = NQ = sp_ld, which every 4- and 8-lane pass has), and the first pieces of it are in flight before the chain bucket
+// sizes -> my sub-instance -> its x0 is walked.  A queue-fed pass (p.qin: what outgrew the pass before) looks at its queue first.
+template <int G, int RP, int KMAX, int THREADS>
+__device__ __forceinline__ void oct_body_split(const PolParams& p) {
+    constexpr bool SPLIT = true;
+    OCT_LAYOUT
+    (void)sLb; (void)sUb; (void)sD; (void)sBT; (void)sX0; (void)myR; (void)myV; (void)myA; (void)g; (void)li; (void)CH; (void)XCH; (void)NS; (void)RPL;
+    unsigned long long pacc[16] = {};
+    int total = p.B;
+    if (p.qin) { total = *p.qin_count; if ((int)blockIdx.x * IPW >= total) return; }
+    const int sl = p.sp_ld;
+    const int img2 = (CN * n * LD + 5 * CN * NQ + CN * NQ / 2 + CN * (nx + 1) * NQ) >> 1;      // double2 pieces of the image
+    constexpr int IMG_U = 4;
+    double2 img[IMG_U];
+    if (sl == NQ) {
+#pragma unroll
+        for (int u = 0; u < IMG_U; ++u) {
+            const int idx = tid + u * THREADS;
+            img[u] = idx < img2 ? reinterpret_cast<const double2*>(p.sp_img)[idx] : make_double2(0.0, 0.0);
+        }
+    }
+    const int slot = blockIdx.x * IPW + li;
+    int sub = 0;
+    if (!p.qin && p.seg) {      // my place in the cold-start order (largest bucket first) -> bucket and offset, from the buckets' sizes;
+        int bk = 0, off = 0, acc = 0;       // split_key_kernel queued only the components with something to do
+#pragma unroll
+        for (int k = NBIN - 1; k >= 0; --k) {        // only the buckets this launch is given (the others run beside it)
+            const int c = (k >= p.seg_lo && k <= p.seg_hi) ? p.seg_counts[k * BIN_STRIDE] : 0;
+            if (slot >= acc && slot < acc + c) { bk = k; off = slot - acc; }
+            acc += c;
+        }
+        total = acc;
+        if ((int)blockIdx.x * IPW >= total) return;
+        sub = slot < total ? p.seg[(size_t)bk * p.B + off] : 0;
+    } else if (slot < total) sub = p.qin ? p.qin[slot] : slot;
+    const int inst = sub / CN, comp = sub - inst * CN;
+    double xpre[64 / G];
+#pragma unroll
+    for (int u = 0; u < 64 / G; ++u) { const int c = g + u * G; xpre[u] = (slot < total && c < nx) ? p.x0[(size_t)inst * nx + c] : 0.0; }
+    if (sl == NQ) {
+#pragma unroll
+        for (int u = 0; u < IMG_U; ++u) { const int idx = tid + u * THREADS; if (idx < img2) reinterpret_cast<double2*>(sHi)[idx] = img[u]; }
+        for (int base = tid + IMG_U * THREADS; base < img2; base += IMG_U * THREADS) {
+            double2 v[IMG_U];
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) { const int idx = base + u * THREADS; v[u] = idx < img2 ? reinterpret_cast<const double2*>(p.sp_img)[idx] : make_double2(0.0, 0.0); }
+#pragma unroll
+            for (int u = 0; u < IMG_U; ++u) { const int idx = base + u * THREADS; if (idx < img2) reinterpret_cast<double2*>(sHi)[idx] = v[u]; }
+        }
+    } else {                // a pass whose LDS rows are wider than the packed ones (16 lanes, components of <= 16 rows)
+        for (int idx = tid; idx < CN * n * LD; idx += THREADS) { const int r = idx / LD, j = idx - r * LD; sHi[idx] = j < sl ? p.Hi[(size_t)r * sl + j] : 0.0; }
+        for (int idx = tid; idx < CN * (nx + 1) * NQ; idx += THREADS) { const int r = idx / NQ, j = idx - r * NQ; sKu[idx] = j < sl ? p.KuT[(size_t)r * sl + j] : 0.0; }
+        for (int idx = tid; idx < CN * NQ; idx += THREADS) {
+            const int c = idx / NQ, j = idx - c * NQ;
+            const double lo = j < sl ? p.lbs[c * sl + j] : -1e300, hi = j < sl ? p.ubs[c * sl + j] : 1e300;
+            sLb[idx] = lo; sUb[idx] = hi; sD[idx] = j < sl ? p.d[c * sl + j] : 0.0;
+            const double tol = 1e-12 * bound_scale(lo, hi);
+            sBT[idx] = make_double2(lo - tol, hi + tol);
+            sPerm[idx] = j < sl ? p.sp_perm[c * sl + j] : -1;
+        }
+    }
+    oct_block<G, RP, KMAX, THREADS, true, true>(p, slot, total, pacc, inst, xpre, sub, comp);
+#ifdef POLISH_PROF
+    if (lane == 0 && p.prof) {
+        unsigned long long tot = 0;
+        for (int i = 0; i < 16; ++i) { atomicAdd(p.prof + (G >= 16 ? 16 : 0) + i, pacc[i]); if (i != 7 && i != 8 && i != 14) tot += pacc[i]; }
+        atomicMax(p.prof + (G >= 16 ? 16 : 0) + 15, tot);
+    }
+#endif
 }
 
-template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT = false>
+// WPS: waves per SIMD the register allocation has to leave room for (HIP's second launch bound); the split passes want two
+// workgroups per CU so that one's start-up latency (bucket sizes -> sub-instance -> x0, the staging) hides behind the other's work
+template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT = false, int WPS = THREADS / 256>
+__global__ __launch_bounds__(THREADS, WPS) void polish_oct_kernel(PolParams p) {
+    if constexpr (SPLIT) oct_body_split<G, RP, KMAX, THREADS>(p);
+    else oct_body<G, RP, KMAX, THREADS, COLD, false>(p);
+}
+
+template <int G, int RP, int KMAX, int THREADS, bool COLD, bool SPLIT = false, int WPS = THREADS / 256>
 int launch_oct_c(const PolParams& p, int ninst, hipStream_t st) {
     constexpr int NQ = 2 * G * RP, LD = NQ, IPW = THREADS / G;
     if (!p.Cq) return -1;
@@ -1043,9 +1080,9 @@ int launch_oct_c(const PolParams& p, int ninst, hipStream_t st) {
     const size_t kux = CN * (p.nx + 1) * NQ * 8 + x0s;
     const size_t lds = (CN * p.n * LD + 5 * CN * NQ + (SPLIT ? CN * NQ / 2 : 0)) * 8 + (kux > xch ? kux : xch);
     if (lds > 160 * 1024) return -1;
-    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS, COLD, SPLIT>), lds);
+    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_oct_kernel<G, RP, KMAX, THREADS, COLD, SPLIT, WPS>), lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS, COLD, SPLIT>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
+    hipLaunchKernelGGL((polish_oct_kernel<G, RP, KMAX, THREADS, COLD, SPLIT, WPS>), dim3(ceil_div(ninst, IPW)), dim3(THREADS), lds, st, p);
     return (int)hipGetLastError();
 }
 
@@ -1074,9 +1111,14 @@ int launch_oct_rp(const PolParams& p, int ninst, hipStream_t st) {
 // slots; rows per lane from the component size p.n.  -1 if the shape has no instantiation.
 int launch_oct_split(const PolParams& p, int slots, hipStream_t st) {
     const int n = p.n;
+    // first pass: 8 lanes per sub-instance and room for two workgroups per CU (one's start-up hides behind the other's work).
+    // Measured and dropped (65,536 instances of configs[2], first pass 136 us): 4 lanes per sub-instance (16 per wave: 181 VGPRs,
+    // or 120 spilled at the 128 this occupancy needs: 144 / 187 us); 256-thread workgroups (154 us: twice the staging);
+    // wave-persistent workgroups with the next unit's data prefetched (146 - 184 us: the loop around the solve costs more
+    // registers than its prologue saves)
     if (slots == 8) {
-        if (n <= 16) return launch_oct_c<8, 1, 8, 512, true, true>(p, p.B, st);
-        if (n <= 32) return launch_oct_c<8, 2, 8, 512, true, true>(p, p.B, st);
+        if (n <= 16) return launch_oct_c<8, 1, 8, 512, true, true, 4>(p, p.B, st);
+        if (n <= 32) return launch_oct_c<8, 2, 8, 512, true, true, 4>(p, p.B, st);
         if (n <= 64) return launch_oct_c<8, 4, 8, 512, true, true>(p, p.B, st);
     } else if (slots == 16) {
         if (n <= 16) return launch_oct_c<8, 1, 16, 512, true, true>(p, p.B, st);
@@ -1186,6 +1228,151 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
     if (tid < NBIN && hist[tid]) base[tid] = atomicAdd(&bins[tid * BIN_STRIDE], hist[tid]);
     __syncthreads();
     if (mine) seg[(size_t)key * p.B + base[key] + local] = inst;
+}
+
+// First launch of a component-split solve (split.hip).  x_unc = Ku1 [x0; 1] of 16 instances per wave as X Ku1' on MFMA tiles
+// (A = [x0; 1] of the instances, B = 16 rows of the map), so that lane l holds rows 16 t + (l & 15) of instances (l >> 4) + 4 r:
+// 16 lanes cover 16 consecutive rows of an instance and every store below is a run of 128 contiguous bytes.
+//   * a component none of whose rows x_unc violates is solved by x_unc itself: its rows of U (and of the kept state, the
+//     multipliers) are written here, its part of the objective is zero, and it never reaches the active-set kernels;
+//   * the others are put into the bucket of their number of violated rows (what predicts their work), largest first, as
+//     cold_key_kernel does for whole instances.
+// p is the UNSPLIT parameter set (map, bounds, scaling of the whole problem; B instances) plus sp_C, sp_part, sp_steps.
+__global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* rowmap, int* need, int* bins, int* seg) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __shared__ int hist[NBIN];
+    __shared__ int base[NBIN];
+    const int n = p.n, nx = p.nx, C = p.sp_C, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int KS = (nx + 1 + 3) / 4, KP = 4 * KS, NQ = 16 * ((n + 15) / 16);
+    const int XS = KP + 1;
+    double* sKu = reinterpret_cast<double*>(smem);      // (KP, NQ): Ku1 transposed, zero padded
+    double* sLb = sKu + (size_t)KP * NQ;
+    double* sUb = sLb + NQ;
+    double* sDd = sUb + NQ;
+    double* sX = sDd + NQ;                              // (64, XS): [x0; 1; 0..] of this block's instances
+    int* sComp = reinterpret_cast<int*>(sX + 64 * XS);  // (NQ): component of the row
+    {
+        const int hq = NQ / 2, tot2 = KP * hq;
+        constexpr int U = 4;
+        for (int b0 = tid; b0 < tot2; b0 += U * 256) {
+            double2 v[U]; int off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = b0 + u * 256;
+                const bool in = idx < tot2;
+                const int k = in ? idx / hq : 0, j = 2 * (idx - k * hq);
+                off[u] = in ? k * NQ + j : -1;
+                v[u] = (in && k <= nx && j < p.NP) ? *reinterpret_cast<const double2*>(p.KuT + (size_t)k * p.NP + j) : make_double2(0.0, 0.0);
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (off[u] >= 0) *reinterpret_cast<double2*>(sKu + off[u]) = v[u];
+        }
+    }
+    for (int j = tid; j < NQ; j += 256) {
+        sLb[j] = j < n ? p.lbs[j] : -1e300; sUb[j] = j < n ? p.ubs[j] : 1e300; sDd[j] = j < n ? p.d[j] : 0.0;
+        sComp[j] = j < n ? (rowmap[j] >> 16) : 0;
+    }
+    {
+        constexpr int U = 4;
+        for (int b0 = tid; b0 < 64 * KP; b0 += U * 256) {
+            double v[U]; int off[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = b0 + u * 256;
+                const int l = idx / KP, k = idx - l * KP;
+                const int i2 = blockIdx.x * 64 + l;
+                off[u] = l * XS + k;
+                v[u] = (idx < 64 * KP && i2 < p.B) ? (k < nx ? p.x0[(size_t)i2 * nx + k] : (k == nx ? 1.0 : 0.0)) : 0.0;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) if (b0 + u * 256 < 64 * KP) sX[off[u]] = v[u];
+        }
+    }
+    if (tid < NBIN) hist[tid] = 0;
+    __syncthreads();
+    const double* xrow = sX + (size_t)(wave * 16 + col) * XS;
+    const int NT = NQ / 16;
+    d4 acc[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) acc[t] = d4{0, 0, 0, 0};
+    for (int s = 0; s < KS; ++s) {
+        const int k = 4 * s + kq;
+        const double xv = xrow[k];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+            if (t < NT) acc[t] = mfma_f64(xv, sKu[k * NQ + 16 * t + col], acc[t]);
+    }
+    // violated rows per (instance, component): 8-bit fields of one 64-bit word per instance (at most 8 components, 128 rows)
+    unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < NT) {
+            const int row = 16 * t + col;
+            const double lo = sLb[row], hi = sUb[row];
+            const int sh = 8 * sComp[row];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cnt[r] += (unsigned long long)((acc[t][r] > hi) | (acc[t][r] < lo)) << sh;
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) {
+            const unsigned lo32 = __shfl_xor((unsigned)cnt[r], off), hi32 = __shfl_xor((unsigned)(cnt[r] >> 32), off);
+            cnt[r] += ((unsigned long long)hi32 << 32) | lo32;
+        }
+    }
+    const int inst0 = blockIdx.x * 64 + wave * 16;
+    // rows of the components that x_unc solves
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < NT) {
+            const int row = 16 * t + col;
+            const int sh = 8 * sComp[row];
+            const double dd = sDd[row];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int inst = inst0 + kq + 4 * r;
+                if (row < n && inst < p.B && ((cnt[r] >> sh) & 0xFFull) == 0ull) {
+                    const double xv = acc[t][r];
+                    p.U[(size_t)inst * n + row] = dd * xv;
+                    if (p.keep_state) { p.z[(size_t)inst * p.NP + row] = xv; p.w[(size_t)inst * p.NP + row] = 0.0; }
+                    if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0;
+                }
+            }
+        }
+    // one lane per (instance, component): done, or into its bucket
+    int mk[2] = {0, 0}, ml[2] = {0, 0}, ms[2] = {0, 0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int idx = col + 16 * u;
+        if (idx < 4 * C) {
+            const int r = idx / C, comp = idx - r * C;
+            const int inst = inst0 + kq + 4 * r;
+            const unsigned long long cr = r == 0 ? cnt[0] : (r == 1 ? cnt[1] : (r == 2 ? cnt[2] : cnt[3]));
+            const int key = (int)((cr >> (8 * comp)) & 0xFFull);
+            if (inst < p.B) {
+                const int sub = inst * C + comp;
+                if (key == 0) { p.sp_part[sub] = 0.0; p.sp_steps[sub] = 0; need[sub] = 0; }
+                else { mk[u] = min(key, NBIN - 1); ms[u] = sub; ml[u] = atomicAdd(&hist[mk[u]], 1); }
+            }
+        }
+    }
+    __syncthreads();
+    if (tid < NBIN && hist[tid]) base[tid] = atomicAdd(&bins[tid * BIN_STRIDE], hist[tid]);
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (mk[u]) seg[(size_t)mk[u] * ((size_t)p.B * C) + base[mk[u]] + ml[u]] = ms[u];
+}
+
+int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, hipStream_t st) {
+    if (p.sp_C > 8 || p.n > 128) return -1;
+    const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
+    const size_t kl = ((size_t)kp * nq + 3 * nq + 64 * (size_t)(kp + 1)) * sizeof(double) + nq * sizeof(int);
+    if (kl > 64 * 1024) return -1;
+    hipLaunchKernelGGL(split_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, rowmap, need, bins, seg);
+    return (int)hipGetLastError();
 }
 
 // The two fast passes: pass A (8 lanes per instance, KMAX = 16) takes the whole batch (large cold batches: in cold-start

@@ -25,7 +25,7 @@
 #include <vector>
 #include <cmath>
 
-int launch_polish_wave_queue(const PolParams& p, hipStream_t st);   // polish.hip: any-size kernel over a queue of instances
+int launch_split_finish(const PolParams& p, const int* need, int* redo, int* redo_count, hipStream_t st);   // polish.hip: per-instance record, whole-instance redo
 
 namespace {
 
@@ -34,10 +34,10 @@ constexpr int NBIN = 32, BIN_STRIDE = 32;       // as polish_quad.hip (cold-star
 // Hi, the map, the bounds and the scaling of every component, gathered through perm [C][ld] (-1 = padding row)
 __global__ void split_pack_kernel(const double* Hi, const double* KuT, const double* lbs, const double* ubs, const double* d,
                                   const int* perm, int C, int ns, int ld, int n, int NP, int nx1, double* oHi, double* oKuT,
-                                  double* olb, double* oub, double* od) {
+                                  double* olb, double* oub, double* od, double* img) {
     const int gid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    for (int idx = gid; idx < C * ns * ns; idx += gsz) {
-        const int c = idx / (ns * ns), r = (idx / ns) % ns, j = idx % ns;
+    for (int idx = gid; idx < C * ns * ld; idx += gsz) {        // rows of ld doubles, padding columns zero
+        const int c = idx / (ns * ld), r = (idx / ld) % ns, j = idx % ld;
         const int gr = perm[c * ld + r], gj = perm[c * ld + j];
         oHi[idx] = (gr >= 0 && gj >= 0) ? Hi[(size_t)gr * n + gj] : 0.0;
     }
@@ -52,6 +52,32 @@ __global__ void split_pack_kernel(const double* Hi, const double* KuT, const dou
         oub[idx] = gj >= 0 ? ubs[gj] : 1e300;
         od[idx] = gj >= 0 ? d[gj] : 0.0;
     }
+    // the image: Hi (C ns ld) | lbs | ubs | d (C ld each) | (lo - tol, hi + tol) pairs (2 C ld) | perm as ints (C ld / 2 doubles) |
+    // KuT (C nx1 ld) -- OCT_LAYOUT of polish_quad.hip with LD = NQ = ld
+    double* iLb = img + (size_t)C * ns * ld;
+    double* iUb = iLb + C * ld;
+    double* iD = iUb + C * ld;
+    double* iBT = iD + C * ld;
+    int* iPerm = reinterpret_cast<int*>(iBT + 2 * C * ld);
+    double* iKu = iBT + 2 * C * ld + C * ld / 2;
+    for (int idx = gid; idx < C * ns * ld; idx += gsz) {
+        const int c = idx / (ns * ld), r = (idx / ld) % ns, j = idx % ld;
+        const int gr = perm[c * ld + r], gj = perm[c * ld + j];
+        img[idx] = (gr >= 0 && gj >= 0) ? Hi[(size_t)gr * n + gj] : 0.0;
+    }
+    for (int idx = gid; idx < C * ld; idx += gsz) {
+        const int gj = perm[idx];
+        const double lo = gj >= 0 ? lbs[gj] : -1e300, hi = gj >= 0 ? ubs[gj] : 1e300;
+        iLb[idx] = lo; iUb[idx] = hi; iD[idx] = gj >= 0 ? d[gj] : 0.0;
+        const double tol = 1e-12 * bound_scale(lo, hi);
+        iBT[2 * idx] = lo - tol; iBT[2 * idx + 1] = hi + tol;
+        iPerm[idx] = gj;
+    }
+    for (int idx = gid; idx < C * nx1 * ld; idx += gsz) {
+        const int c = idx / (nx1 * ld), k = (idx / ld) % nx1, j = idx % ld;
+        const int gj = perm[c * ld + j];
+        iKu[idx] = gj >= 0 ? KuT[(size_t)k * NP + gj] : 0.0;
+    }
 }
 
 template <typename T>
@@ -63,21 +89,21 @@ int sp_alloc(mpcqp_handle h, T** p, size_t count) {
 }
 
 // int workspace for BC sub-instances of B instances:
-//   need[BC] | queue 1 [BC] | queue 2 [BC] | steps[BC] | done[B] | redo queue [B] | counters (96 + 32 x 32) | buckets [32][BC]
-struct SplitWs { int *need, *q1, *q2, *steps, *done, *failq, *counters, *seg; };
+//   need[BC] | queue 1 [BC] | queue 2 [BC] | steps[BC] | counters (96 + 32 x 32) | buckets [32][BC]
+struct SplitWs { int *need, *q1, *q2, *steps, *counters, *seg; };
 SplitWs split_ws(mpcqp_handle h) {
-    const size_t BC = h->sp_bcap, B = BC / h->sp_C;
+    const size_t BC = h->sp_bcap;
     SplitWs w;
-    w.need = h->sp_iws; w.q1 = w.need + BC; w.q2 = w.q1 + BC; w.steps = w.q2 + BC; w.done = w.steps + BC;
-    w.failq = w.done + B; w.counters = w.failq + B; w.seg = w.counters + 96 + NBIN * BIN_STRIDE;
+    w.need = h->sp_iws; w.q1 = w.need + BC; w.q2 = w.q1 + BC; w.steps = w.q2 + BC;
+    w.counters = w.steps + BC; w.seg = w.counters + 96 + NBIN * BIN_STRIDE;
     return w;
 }
 
 int split_ensure_batch(mpcqp_handle h, int B) {
     const int need = ceil_div(B, 64) * 64 * h->sp_C;
     if (need <= h->sp_bcap) return MPCQP_OK;
-    const size_t BC = need, Bi = BC / h->sp_C;
-    int rc = sp_alloc(h, &h->sp_iws, 4 * BC + 2 * Bi + 96 + NBIN * BIN_STRIDE + (size_t)NBIN * BC);
+    const size_t BC = need;
+    int rc = sp_alloc(h, &h->sp_iws, 4 * BC + 96 + NBIN * BIN_STRIDE + (size_t)NBIN * BC);
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_part, BC);
     // hand-over records (polish_quad.hip): K*K + 4K + 2 doubles for K slots; sized for half (a quarter) of the sub-instances
     // outgrowing 8 (16) slots -- beyond that a sub-instance starts its next pass from the empty set
@@ -85,17 +111,17 @@ int split_ensure_batch(mpcqp_handle h, int B) {
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_hb1, (size_t)h->sp_cap1 * (8 * 8 + 4 * 8 + 2));
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_hb2, (size_t)h->sp_cap2 * (16 * 16 + 4 * 16 + 2));
     if (rc != MPCQP_OK) { h->sp_bcap = 0; return rc; }
-    h->sp_bcap = need;
+    h->sp_bcap = need; h->sp_wsC = h->sp_C; h->sp_wsld = h->sp_ld;
     return MPCQP_OK;
 }
 
 }  // namespace
 
 void split_free(mpcqp_handle h) {
-    void* ptrs[] = {h->sp_perm, h->sp_rowmap, h->sp_Hi, h->sp_KuT, h->sp_lbs, h->sp_ubs, h->sp_d, h->sp_iws, h->sp_part, h->sp_hb1, h->sp_hb2};
+    void* ptrs[] = {h->sp_perm, h->sp_rowmap, h->sp_Hi, h->sp_KuT, h->sp_lbs, h->sp_ubs, h->sp_d, h->sp_img, h->sp_iws, h->sp_part, h->sp_hb1, h->sp_hb2};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->sp_perm = h->sp_rowmap = h->sp_iws = nullptr;
-    h->sp_Hi = h->sp_KuT = h->sp_lbs = h->sp_ubs = h->sp_d = h->sp_part = h->sp_hb1 = h->sp_hb2 = nullptr;
+    h->sp_Hi = h->sp_KuT = h->sp_lbs = h->sp_ubs = h->sp_d = h->sp_img = h->sp_part = h->sp_hb1 = h->sp_hb2 = nullptr;
     h->sp_C = h->sp_ns = h->sp_ld = h->sp_bcap = 0;
 }
 
@@ -128,14 +154,14 @@ int split_setup(mpcqp_handle h, hipStream_t st) {
         comp_of[i] = comp_of[r];
         ++size[comp_of[i]];
     }
-    if (C < 2 || C > 32) return MPCQP_OK;
+    if (C < 2 || C > 8) return MPCQP_OK;        // split_key_kernel counts violated rows per component in 8-bit fields of one word
     int ns = *std::max_element(size.begin(), size.end());
     ns += ns & 1;                               // even: 16-byte rows in the staging loops
     if (ns > 64) return MPCQP_OK;               // what the SPLIT instantiations hold (polish_quad.hip: launch_oct_split)
-    const int ld = 16 * ceil_div(ns, 16);
+    const int ld = ns <= 16 ? 16 : (ns <= 32 ? 32 : 64);     // = the LDS row of the 8-lane passes (polish_quad.hip: NQ), so that staging is a flat copy
     {   // LDS of the widest pass must fit (the formula of launch_oct_c): otherwise the split is not worth having
         const size_t NQ = ns <= 16 ? 16 : (ns <= 32 ? 32 : 64);
-        const size_t kux = (size_t)C * nx1 * NQ * 8 + 64 * (size_t)h->dims.nx * 8, xch = 64 * 36 * 20;
+        const size_t kux = (size_t)C * nx1 * NQ * 8 + 128 * (size_t)h->dims.nx * 8, xch = 128 * 12 * 20;   // 4-lane pass: 128 sub-instances per workgroup
         const size_t lds = ((size_t)C * ns * NQ + 5 * C * NQ + C * NQ / 2) * 8 + std::max(kux, xch);
         if (lds > 150 * 1024) return MPCQP_OK;
     }
@@ -151,16 +177,16 @@ int split_setup(mpcqp_handle h, hipStream_t st) {
     HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->sp_rowmap), rowmap.size() * sizeof(int)));
     HIPCHK(h, hipMemcpy(h->sp_perm, perm.data(), perm.size() * sizeof(int), hipMemcpyHostToDevice));
     HIPCHK(h, hipMemcpy(h->sp_rowmap, rowmap.data(), rowmap.size() * sizeof(int), hipMemcpyHostToDevice));
-    int rc = sp_alloc(h, &h->sp_Hi, (size_t)C * ns * ns);
+    int rc = sp_alloc(h, &h->sp_Hi, (size_t)C * ns * ld);
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_KuT, (size_t)C * nx1 * ld);
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_lbs, (size_t)C * ld);
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_ubs, (size_t)C * ld);
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_d, (size_t)C * ld);
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_img, (size_t)C * ns * ld + 5 * (size_t)C * ld + (size_t)C * ld / 2 + (size_t)C * nx1 * ld + 2);
     if (rc != MPCQP_OK) return rc;
     hipLaunchKernelGGL(split_pack_kernel, dim3(64), dim3(256), 0, st, h->Hi, h->KuT, h->lbs, h->ubs, h->d, h->sp_perm, C, ns,
-                       ld, n, h->NP, nx1, h->sp_Hi, h->sp_KuT, h->sp_lbs, h->sp_ubs, h->sp_d);
+                       ld, n, h->NP, nx1, h->sp_Hi, h->sp_KuT, h->sp_lbs, h->sp_ubs, h->sp_d, h->sp_img);
     HIPCHK(h, hipGetLastError());
-    if (h->sp_bcap && (h->sp_bcap % C != 0 || C != h->sp_C)) h->sp_bcap = 0;      // workspace of another component count: size it again
     h->sp_C = C; h->sp_ns = ns; h->sp_ld = ld;
     return MPCQP_OK;
 }
@@ -169,26 +195,38 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     if (h->sp_C < 2 || !pin.cold || !pin.polish || pin.refine > 0 || pin.st_nn || !pin.Cq) return -1;
     const int C = h->sp_C, Binst = pin.B;
     if ((long)Binst * C > (1L << 30)) return -1;
-    if (h->sp_bcap && h->sp_bcap % C != 0) h->sp_bcap = 0;
+    if (h->sp_bcap && (h->sp_wsC != C || h->sp_wsld != h->sp_ld)) h->sp_bcap = 0;     // workspace of another split: size it again
     int rc = split_ensure_batch(h, Binst);
     if (rc != MPCQP_OK) return (int)hipErrorOutOfMemory;
     const SplitWs w = split_ws(h);
     hipError_t e = hipMemsetAsync(w.counters, 0, (96 + NBIN * BIN_STRIDE) * sizeof(int), st);
     if (e != hipSuccess) return (int)e;
     PolParams p = pin;
-    p.sp_C = C; p.sp_ld = h->sp_ld; p.sp_n = pin.n; p.sp_NP = pin.NP; p.sp_perm = h->sp_perm;
-    p.sp_part = h->sp_part; p.sp_steps = w.steps; p.sp_done = w.done; p.sp_failq = w.failq; p.sp_failq_count = w.counters + 2;
+    p.sp_C = C; p.sp_ld = h->sp_ld; p.sp_n = pin.n; p.sp_NP = pin.NP; p.sp_perm = h->sp_perm; p.sp_img = h->sp_img;
+    p.sp_part = h->sp_part; p.sp_steps = w.steps;
     p.Hi = h->sp_Hi; p.KuT = h->sp_KuT; p.lbs = h->sp_lbs; p.ubs = h->sp_ubs; p.d = h->sp_d;
     p.n = h->sp_ns; p.B = Binst * C;
     p.need_big = w.need;
     p.seg = nullptr; p.seg_counts = nullptr; p.q_gate = 0; p.hand_zw = 0;
-    // 8 slots -> 16 -> 32, each pass taking the queue (and the working states) the one before left
+    // x_unc for everyone: components it solves are finished there, the rest ordered by the number of rows it violates
+    {
+        PolParams k = pin;
+        k.sp_C = C; k.sp_part = h->sp_part; k.sp_steps = w.steps;
+        rc = launch_split_key(k, h->sp_rowmap, w.need, w.counters + 96, w.seg, st);
+        if (rc != 0) return rc;
+    }
+    if (stop_after == 2) return 0;
+    // 8 slots -> 16 -> 32, each pass taking the queue (and the working states) the one before left.
+    // (Measured and dropped: components that violate 6 rows or more -- they outgrow 8 slots almost surely -- started in the 16-slot
+    // pass on a second stream BESIDE the first pass: the fork / join through events cost ~40 us of gaps per solve, more than the
+    // 35 us the queue-fed 16-slot pass lasts.)
     PolParams a = p;
+    a.seg = w.seg; a.seg_counts = w.counters + 96; a.seg_lo = 1; a.seg_hi = NBIN - 1;
     a.qin = nullptr; a.qin_count = nullptr; a.qout = w.q1; a.qout_count = w.counters;
     a.hand_in = nullptr; a.hand_out = h->sp_hb1; a.hand_out_cap = h->sp_cap1;
     rc = launch_oct_split(a, 8, st);
     if (rc != 0) return rc;
-    if (stop_after == 1) return 0;
+    if (stop_after == 1) return 0;      // timing of the first pass alone (bench.py): the batch is left partly solved
     PolParams b = p;
     b.qin = w.q1; b.qin_count = w.counters; b.qout = w.q2; b.qout_count = w.counters + 1;
     b.hand_in = h->sp_hb1; b.hand_out = h->sp_hb2; b.hand_out_cap = h->sp_cap2;
@@ -199,10 +237,12 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     c.hand_in = h->sp_hb2; c.hand_out = nullptr; c.hand_out_cap = 0;
     rc = launch_oct_split(c, 32, st);
     if (rc != 0) return rc;
-    // instances with a component the cascade could not finish (more than 32 active rows in a component of more than 32 rows, or
-    // a numerical guard): the whole instance again, unsplit, from the empty set, by the any-size kernel
+    // the instances' records from their components' parts; an instance with a component the cascade could not finish (more than
+    // 32 active rows in a component of more than 32 rows, or a numerical guard) is solved again as a whole, unsplit, from the
+    // empty set, by the any-size kernel
     PolParams f = pin;
-    f.pass = 1; f.qin = w.failq; f.qin_count = w.counters + 2; f.qout = nullptr; f.qout_count = nullptr;
+    f.pass = 1; f.qin = nullptr; f.qin_count = nullptr; f.qout = nullptr; f.qout_count = nullptr;
     f.hand_in = nullptr; f.hand_out = nullptr; f.hand_zw = 0; f.seg = nullptr;
-    return launch_polish_wave_queue(f, st);
+    f.sp_C = C; f.sp_part = h->sp_part; f.sp_steps = w.steps;
+    return launch_split_finish(f, w.need, w.q1, w.counters + 2, st);      // queue 1 is free again
 }

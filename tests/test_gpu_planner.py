@@ -13,9 +13,10 @@ PRIMAL_RTOL = 1e-6
 OBJ_RTOL = 1e-8
 
 
-def _planner(prob):
+def _planner(prob, split=True):
     from mpc_amd.planner import Planner
     pl = Planner(prob["nx"], prob["nu"], prob["N"])
+    pl.split = split                # False: the kernels that take the instance as a whole (what a coupled model runs)
     pl.set_model(prob["A"], prob["B"])
     pl.set_cost(prob["Q"], prob["R"], prob["P"])
     pl.set_constraints(prob["u_min"], prob["u_max"])
@@ -48,12 +49,17 @@ def test_assembly_matches_oracle(cfg, golden_dir):
     assert np.abs(pl.get("Phi").cpu().numpy() - Phi).max() <= 1e-13 * np.abs(Phi).max()
 
 
+# split: configs[2] (cfg 3) is four independent chains and is solved component by component unless told otherwise; the
+# other two are coupled, so the flag changes nothing for them
+SPLIT_CASES = [(1, True), (2, True), (3, True), (3, False)]
+
+
 @pytest.mark.parametrize("admm", [0, 5])          # active-set kernels alone (the default) / after five ADMM iterations
-@pytest.mark.parametrize("cfg", [1, 2, 3])
-def test_solve_matches_golden(cfg, admm, golden_dir):
+@pytest.mark.parametrize("cfg,split", SPLIT_CASES)
+def test_solve_matches_golden(cfg, split, admm, golden_dir):
     g = np.load(os.path.join(golden_dir, f"mpc_cfg{cfg}.npz"))
     prob = _prob_from_golden(g)
-    pl = _planner(prob)
+    pl = _planner(prob, split)
     U = pl.solve(prob["x0"], want_multipliers=True, max_iter=admm).cpu().numpy().reshape(len(prob["x0"]), -1)
     info = pl.info
     assert (info.iters.cpu().numpy() == admm).all()
@@ -68,14 +74,16 @@ def test_solve_matches_golden(cfg, admm, golden_dir):
 
 
 @pytest.mark.parametrize("admm", [0, 2, 5])
-@pytest.mark.parametrize("cfg,batch,scale", [(1, 64, 1.0), (2, 96, 8.0), (3, 200, 1.0), (3, 72, 3.0)])
-def test_solve_matches_oracle_seeded(cfg, batch, scale, admm):
+@pytest.mark.parametrize("cfg,batch,scale,split", [(1, 64, 1.0, True), (2, 96, 8.0, True), (3, 200, 1.0, True), (3, 72, 3.0, True),
+                                                   (3, 200, 1.0, False), (3, 72, 3.0, False)])
+def test_solve_matches_oracle_seeded(cfg, batch, scale, split, admm):
     from mpc_amd.configs import make_config
     from oracle import mpc_oracle as mo
     from oracle.qp_oracle import solve_box_qp
     prob = make_config(cfg, batch=batch, seed=7)
     prob["x0"] = prob["x0"] * scale
-    pl = _planner(prob)
+    pl = _planner(prob, split)
+    assert pl.setup().split_info()["components"] == (4 if cfg == 3 and split else 0)
     U = pl.solve(prob["x0"], max_iter=admm).cpu().numpy().reshape(batch, -1)
     assert (pl.info.status.cpu().numpy() == 0).all()
     H, F, f0 = mo.condense(prob)
@@ -210,14 +218,15 @@ def test_no_sync_factor_failure_is_reported_as_status():
         assert (pl.info.status.cpu().numpy() == _lib.SOLVED).all()
 
 
-def test_two_handles_on_two_streams_do_not_disturb_each_other():
+@pytest.mark.parametrize("split", [True, False])
+def test_two_handles_on_two_streams_do_not_disturb_each_other(split):
     """The serving pattern bench.py reports beside `value`: two handles, two streams, solves in flight together.  Every
     handle owns its queues, counters and hand-over records, so the answers are those of the same solves one by one
     (bit for bit: the cascade is deterministic per instance)."""
     import torch
     from mpc_amd.configs import make_config
     probs = [make_config(3, batch=30000, seed=5), make_config(3, batch=26000, seed=6)]
-    pls = [_planner(p).setup() for p in probs]
+    pls = [_planner(p, split).setup() for p in probs]
     xs = [torch.as_tensor(1.4 * p["x0"], device="cuda:0") for p in probs]       # long queues in every pass
     ref = [pl.solve(x).clone() for pl, x in zip(pls, xs)]
     # reproducible bit for bit from solve to solve, although the cold-start order (atomic cursors) puts an instance next to
@@ -239,14 +248,15 @@ def test_two_handles_on_two_streams_do_not_disturb_each_other():
         assert torch.equal(outs[i], ref[i])
 
 
+@pytest.mark.parametrize("split", [True, False])
 @pytest.mark.parametrize("kw", [{}, {"max_iter": 10}], ids=["cold", "admm-first"])
-def test_an_instance_does_not_depend_on_its_neighbours(kw):
+def test_an_instance_does_not_depend_on_its_neighbours(kw, split):
     """The same instances in another order (other neighbours and another place in the wave): bit for bit the same answers.
     (The warm start once listed its guessed rows in the order of the lane's registers, which depends on the place.)"""
     import torch
     from mpc_amd.configs import make_config
     prob = make_config(3, batch=9000, seed=1)
-    pl = _planner(prob).setup()
+    pl = _planner(prob, split).setup()
     x = torch.as_tensor(1.5 * prob["x0"], device="cuda:0")
     perm = torch.randperm(9000, device="cuda:0", generator=torch.Generator(device="cuda:0").manual_seed(3))
     Ua = pl.solve(x, **kw).clone()
@@ -328,10 +338,11 @@ def test_horizon_beyond_128_inputs_goes_to_the_dense_kernel():
         assert np.abs(U[i] - s["x"]).max() <= 1e-6 * max(1.0, np.abs(s["x"]).max())
 
 
-def test_ragged_and_tiny_batches():
+@pytest.mark.parametrize("split", [True, False])
+def test_ragged_and_tiny_batches(split):
     from mpc_amd.configs import make_config
     prob = make_config(3, batch=131, seed=2)
-    pl = _planner(prob)
+    pl = _planner(prob, split)
     Uall = pl.solve(prob["x0"]).cpu().numpy()
     for b in (1, 15, 17, 63, 65):
         Ub = pl.solve(prob["x0"][:b]).cpu().numpy()
@@ -376,8 +387,10 @@ def _assert_kkt_everywhere(pl, x0, U, u_min, u_max, N):
     return free
 
 
-@pytest.mark.parametrize("cfg,batch,x0_scale", [(2, 4096, 1.0), (3, 65536, 1.0), (3, 8192, 2.5), (3, 16384, 2.5)])
-def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale):
+@pytest.mark.parametrize("cfg,batch,x0_scale,split", [(2, 4096, 1.0, True), (3, 65536, 1.0, True), (3, 8192, 2.5, True),
+                                                      (3, 16384, 2.5, True), (3, 65536, 1.0, False), (3, 8192, 2.5, False),
+                                                      (3, 16384, 2.5, False)])
+def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale, split):
     """BASELINE.json's full sizes (4,096 cart-poles; 65,536 quadrotors): the oracle cannot visit every instance in
     seconds, so parity at this size is the solver-independent optimality certificate, evaluated for ALL instances."""
     import torch
@@ -385,7 +398,7 @@ def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale):
     prob = make_config(cfg, batch=batch, seed=1)
     # scale 2.5: far-out initial states -- large active sets, so most instances outgrow the first pass, many the second and
     # a few the third; at 16,384 instances the second pass's queue is long enough for its 16-lane instantiation
-    pl = _planner(prob)
+    pl = _planner(prob, split)
     x0 = torch.as_tensor(prob["x0"] * x0_scale, device="cuda:0")
     U = pl.solve(x0).reshape(batch, -1)
     free = _assert_kkt_everywhere(pl, x0, U, prob["u_min"], prob["u_max"], prob["N"])
@@ -394,8 +407,13 @@ def test_full_size_batches_satisfy_kkt_everywhere(cfg, batch, x0_scale):
     if x0_scale > 1.0:
         nact = (~free).sum(1)
         assert int((nact > 16).sum()) > batch // 20 and int(nact.max()) > 32     # every pass of the chain is exercised
-        queued = int(pl.get("queues")[0].item())
-        assert (queued >= 8192) == (batch >= 16384)          # which second-pass instantiation ran (polish_quad.hip, LONG_QUEUE)
+        if not split:
+            queued = int(pl.get("queues")[0].item())
+            assert (queued >= 8192) == (batch >= 16384)      # which second-pass instantiation ran (polish_quad.hip, LONG_QUEUE)
+        else:       # per component: two of the four chains carry the load, and some of them bind on more than 16 rows
+            rm = torch.as_tensor(pl.split_info()["row_map"], device="cuda:0")
+            per = torch.stack([((~free) & (rm == c)).sum(1) for c in range(4)], 1)
+            assert int((per > 8).sum()) > batch // 4 and int(per.max()) > 16
 
 
 def test_long_queue_second_pass_on_an_odd_shape():
