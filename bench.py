@@ -36,11 +36,18 @@ sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6      # MI355X fp64 vector = matrix peak (MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
-# HBM bytes per launch at 65,536 instances from the committed PMC passes (2 * FETCH_SIZE + WRITE_SIZE, KB -> bytes)
+LDS_PEAK_GBS = 256 * 256 * 2.4          # 256 CUs x 256 B/clk (ds_read_b64 / b128, MI355X_MICROARCH.md, LDS) x 2.4 GHz = 157 TB/s
+# counters of the dominant kernels at 65,536 instances from the committed PMC passes (tools/pmc_summary.py;
+# HBM bytes = 2 * FETCH_SIZE + WRITE_SIZE, KB -> bytes, the guide's gfx950 correction)
 PMC = {
     "admm": ((2 * 49314.40 + 213303.90) * 1024.0, "profiles/r01_v5_pmc.csv (admm_shared_box_kernel)"),
     "pass_a": ((2 * 7575.72 + 195238.18) * 1024.0, "profiles/r02_pmc.csv (polish_oct_kernel<8, 8, 16, 512, true>, the first pass)"),
 }
+try:
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_headline.json")) as _f:      # written by tools/pmc_headline.py from the r03 passes
+        PMC_R03 = json.load(_f)
+except (OSError, ValueError):
+    PMC_R03 = None
 
 
 def parse_args(argv=None):
@@ -56,6 +63,10 @@ def parse_args(argv=None):
     ap.add_argument("--no-shard-sweep", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--max-iter", type=int, default=None)
+    ap.add_argument("--keep-state", type=int, default=0, choices=[0, 1],
+                    help="configs 2/3: 1 = every solve also leaves its (z, w) warm-start state in the handle (default 0: a cold "
+                         "batch solve, SURVEY.md 8(d)'s 1,072 B/solve case; the other one is reported as with_state_ms)")
+    ap.add_argument("--no-split", action="store_true", help="configs 2/3: solve block-diagonal models as a whole (split off)")
     ap.add_argument("--rho", type=float, default=None)
     args = ap.parse_args(argv)
     if args.steps is None:
@@ -122,6 +133,25 @@ def cpu_baseline_box(prob, seconds, what):
                      f"default tolerances, mean {float(it.mean()):.1f} iterations, {bad} not optimal; "
                      f"single-core {per_core:.0f} solves/s",
            "single_core": per_core}
+    # single-instance latency of the IPM port, one core: p50 over 101 solves of different x0
+    lat = []
+    for i in range(101):
+        _, _, _, ti = cb.solve_batch_box(H, F, f0, lb, ub, prob["x0"][i:i + 1], nthreads=1)
+        lat.append(ti)
+    out["single_instance_p50_ms"] = sorted(lat)[50] * 1e3
+    # the ADMM of admm_shared.hip as a NumPy restatement (batched GEMM form, OpenBLAS on all cores): a FIXED 200 iterations,
+    # which reach eps 1e-3-1e-4 on this workload -- ADMM alone does not reach the 1e-6 bar in any sane budget
+    try:
+        ns3 = int(min(len(prob["x0"]), 4096)); K3 = 200
+        fac = mo.factor(H, F, f0, lb, ub, 1.0)
+        rho3 = 0.1 * float(np.sqrt(np.abs(fac["Hs"]).sum(1).max() / np.abs(fac["Hi"]).sum(1).max()))     # the rule of mpcqp_factor
+        fac = mo.factor(H, F, f0, lb, ub, rho3)
+        t3 = time.perf_counter(); _, _, rp, rd = mo.admm_box(fac, prob["x0"][:ns3], K3, return_residuals=True); t3 = time.perf_counter() - t3
+        out["cpu_admm"] = {"value": ns3 / t3, "unit": "solves/s", "iterations": K3, "cores": cores,
+                           "what": f"oracle/mpc_oracle.admm_box (NumPy, the GPU ADMM kernel's iteration) on {ns3} x0, {K3} "
+                                   f"iterations each; residuals reached: primal {float(np.median(rp)):.1e}, dual {float(np.median(rd)):.1e} (median)"}
+    except Exception as e:      # noqa: BLE001
+        out["cpu_admm"] = {"value": None, "what": f"failed: {e!r}"}
     if hasattr(cb, "solve_batch_box_activeset"):
         try:
             ns2 = int(min(len(prob["x0"]), 8 * nsamp))
@@ -288,6 +318,8 @@ class BoxWorkload:
         self.B = hi - lo
         dev = ranks.dev
         self.pl = pl = Planner(prob["nx"], prob["nu"], prob["N"], device=dev)
+        pl.split = not args.no_split
+        pl.opts.keep_state = args.keep_state
         pl.set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
         pl.set_constraints(prob["u_min"], prob["u_max"])
         torch.cuda.synchronize(dev)
@@ -312,6 +344,7 @@ class BoxWorkload:
             self.ranks.flag_allreduce(self.pl.info.status)
 
     def report(self, dt):
+        import numpy as np
         args, ranks, torch, pl, prob = self.args, self.ranks, self.torch, self.pl, self.prob
         dev, B, x0, opts = ranks.dev, self.B, self.x0, self.opts
         timed = device_timer(torch, dev)
@@ -327,7 +360,9 @@ class BoxWorkload:
         # ordering kernels that run before it (diagnostic modes: queued instances stay open)
         # (the ordering kernel only runs for cold batches of more than 16,384 instances, polish_quad.hip; below that "stages=15"
         # times an empty solve, i.e. the host's launch cost, which is not something to subtract from a kernel time)
-        ordered = B > 16384 and not admm_on
+        split = pl.split_info()
+        ncomp = split["components"]
+        ordered = (B > 16384 or ncomp > 0) and not admm_on
         order_ms = max(timed(lambda: pl.solve(x0, stages=15, **opts), reps) - admm_ms, 0.0) if ordered else 0.0
         pass_a_ms = max(timed(lambda: pl.solve(x0, stages=7, **opts), reps) - admm_ms - order_ms, 0.0)
         nlat = max(20, min(args.steps, 100))
@@ -362,6 +397,7 @@ class BoxWorkload:
         if ranks.world == 1 and not args.no_shard_sweep and args.config == 3:
             from mpc_amd.planner import Planner
             pl2 = Planner(prob["nx"], prob["nu"], prob["N"], device=dev)
+            pl2.split = pl.split; pl2.opts.keep_state = args.keep_state
             pl2.set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
             pl2.set_constraints(prob["u_min"], prob["u_max"]).setup(rho=args.rho)
             pl2.reuse_outputs = True
@@ -381,6 +417,44 @@ class BoxWorkload:
             del pl2
 
         n = pl.n
+        # the other state mode, beside `value`'s
+        pl.opts.keep_state = 1 - args.keep_state
+        other_ms = timed(lambda: pl.solve(x0, **opts), reps)
+        pl.opts.keep_state = args.keep_state
+        pl.solve(x0, **opts)
+        # ---- three fractions for the timed region; the binding roofline is the largest ------------------
+        # work actually executed by the active-set method, from the solution itself: a component (the whole instance when the
+        # model does not split) of r rows that ends with a active rows took ~a add steps at working-set sizes k = 0..a-1, each
+        #   x-update 2 r (k+1) + direction 2 k^2 + rank-one update of S^-1 2 (k+1)^2 + scan 3 r   flops,
+        #   8 r (k+1) bytes of Hi rows read from LDS for the x-update (the other LDS reads are O(k)).
+        lbv = torch.as_tensor(np.tile(prob["u_min"], prob["N"]), device=dev); ubv = torch.as_tensor(np.tile(prob["u_max"], prob["N"]), device=dev)
+        Uf = self.U.reshape(B, -1)
+        act = ((Uf >= ubv - 1e-9 * ubv.abs().clamp_min(1.0)) | (Uf <= lbv + 1e-9 * lbv.abs().clamp_min(1.0))).double()
+        if ncomp > 0:
+            rm = torch.as_tensor(split["row_map"], device=dev)
+            a_c = torch.stack([act[:, rm == c].sum(1) for c in range(ncomp)], 1)      # active rows per (instance, component)
+            r_c = float(split["rows"])
+        else:
+            a_c = act.sum(1, keepdim=True); r_c = float(n)
+        as_flops = float((r_c * a_c * (a_c + 1) + (4.0 / 3.0) * a_c ** 3 + 2.0 * a_c ** 2 + 3.0 * r_c * (a_c + 1)).sum().item())
+        as_flops += B * (2.0 * n * (prob["nx"] + 1))                                    # x_unc = Ku1 [x0; 1]
+        lds_bytes = float((4.0 * r_c * a_c * (a_c + 1)).sum().item())
+        t_s = both_ms * 1e-3
+        compulsory = B * (8 * prob["nx"] + 8 * n + 16)                                   # x0 in; U, (iters, status, objective) out
+        state_bytes = B * 2 * 8 * 16 * ((n + 15) // 16) if args.keep_state else 0       # (z, w) written when the state is kept
+        fr_hbm = (compulsory + state_bytes) / t_s / 1e9 / HBM_PEAK_GBS
+        fr_fp64 = (as_flops if not admm_on else as_flops + B * iters_mean * (2 * n * n + 10 * (n + n))) / t_s / 1e12 / FP64_PEAK_TFLOPS
+        fr_lds = lds_bytes / t_s / 1e9 / LDS_PEAK_GBS
+        fractions = {"hbm": fr_hbm, "fp64": fr_fp64, "lds": fr_lds,
+                     "binding": max((("hbm", fr_hbm), ("fp64", fr_fp64), ("lds", fr_lds)), key=lambda kv: kv[1])[0],
+                     "bytes_per_solve_compulsory": compulsory / B, "bytes_per_solve_state": state_bytes / B,
+                     "flops_per_solve_executed": as_flops / B, "lds_bytes_per_solve": lds_bytes / B,
+                     "what": "SURVEY.md 8(d): whole timed region (one mpcqp_solve of the batch); hbm = compulsory bytes (x0 in, U + "
+                             "info out, + the (z, w) state when kept) / t / 8 TB/s; fp64 = flops the active-set method executed "
+                             "(from the final active sets, formula in bench.py) / t / 78.6 TF; lds = Hi bytes its x-updates read / t "
+                             "/ 157 TB/s.  All three are small: the solve is a dependent chain of short fp64 steps per (component of "
+                             "an) instance -- VALU-issue and latency bound (valu_active / waves_per_simd below), not a streaming or a "
+                             "GEMM-shaped kernel"}
         if admm_on:
             flops = B * iters_mean * (2 * n * n + 10 * (n + n))         # 2 n^2 + 10 (n + m) per iteration
             tf = flops / (admm_ms * 1e-3) / 1e12
@@ -388,20 +462,25 @@ class BoxWorkload:
                         "unit": "TFLOP/s", "frac": tf / FP64_PEAK_TFLOPS, "traffic": PMC["admm"][0] * B / 65536.0,
                         "traffic_source": PMC["admm"][1] + ", scaled with the batch",
                         "algorithmic_bytes": B * (8 * prob["nx"] + 3 * 8 * 16 * ((n + 15) // 16)),
-                        "flops_per_launch": flops, "launch_ms": admm_ms}
+                        "flops_per_launch": flops, "launch_ms": admm_ms, "fractions": fractions}
         else:
-            # first active-set pass.  Algorithmic bytes per instance: x0 in; U, the (z, w) warm-start state and the info
-            # record out.  It is NOT a streaming kernel (a dependent chain of fp64 steps per instance, DESIGN.md
-            # section 4): the HBM fraction is reported because the contract offers no third bound
-            pa_bytes = B * (8 * prob["nx"] + 8 * n + 2 * 8 * n + 36)
+            # dominant kernel: the first active-set pass.  Its algorithmic bytes: x0 in, U (and the state when kept) out, of the
+            # instances (components) it finishes -- the same per-solve figure, since every instance passes through it or through
+            # the ordering kernel in front of it.  NOT a streaming kernel: the fraction is reported because the contract asks for one
+            pa_bytes = compulsory + state_bytes
             gbs = pa_bytes / (pass_a_ms * 1e-3) / 1e9
-            roofline = {"bound": "hbm", "kernel": "polish_oct_kernel (first active-set pass)", "achieved": gbs,
+            key = "split" if ncomp > 0 else "unsplit"
+            pm = (PMC_R03 or {}).get(key) if args.config == 3 else None
+            roofline = {"bound": "hbm", "kernel": ("polish_oct_kernel<8 lanes, 8 slots, split> (first active-set pass over the components)" if ncomp > 0
+                                                   else "polish_oct_kernel (first active-set pass)"), "achieved": gbs,
                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
-                        "traffic": PMC["pass_a"][0] * B / 65536.0 if args.config == 3 else None,
-                        "traffic_source": PMC["pass_a"][1] + ", scaled with the batch" if args.config == 3 else None,
+                        "traffic": (pm["hbm_bytes_per_launch"] * B / 65536.0 if pm else (PMC["pass_a"][0] * B / 65536.0 if args.config == 3 and ncomp == 0 and args.keep_state else None)),
+                        "traffic_source": (pm["source"] + ", scaled with the batch" if pm else (PMC["pass_a"][1] + ", scaled with the batch" if args.config == 3 and ncomp == 0 and args.keep_state else None)),
                         "algorithmic_bytes": pa_bytes, "launch_ms": pass_a_ms,
-                        "note": "latency / VALU-issue bound by construction: ~8 dependent active-set steps per instance in "
-                                "fp64; VALU busy fraction and instruction counts in DESIGN.md section 4a" +
+                        "valu_active_per_simd": pm.get("valu_active_per_simd") if pm else None,
+                        "waves_per_simd": pm.get("waves_per_simd") if pm else None,
+                        "fractions": fractions,
+                        "note": "latency / VALU-issue bound by construction: dependent active-set steps in fp64 (DESIGN.md section 4b)" +
                                 ("" if B >= 16384 else "; at this batch size the launch is shorter than the host's cost of "
                                  "issuing it (~20 us per launch pair): launch_ms is host-bound")}
         config = {"workload": f"{self.name}, {self.global_batch} random x0 "
@@ -410,7 +489,12 @@ class BoxWorkload:
                   "batch_per_gpu": B, "global_batch": self.global_batch,
                   "parallelism": f"dp{ranks.world} (independent shards, no data-path collective)",
                   "algorithm": ("ADMM (shared (Hs+rho I)^-1, fp64 MFMA GEMM form) + " if admm_on else "") +
-                               "dual active-set kernels (8/32 lanes per instance, explicit S^-1 in registers, Hs^-1 in LDS)",
+                               (f"component split ({ncomp} independent blocks of {split['rows']} rows found in the Hessian): x_unc on MFMA "
+                                "tiles finishes the untouched components, dual active-set kernels take the rest (8 lanes per "
+                                "component, explicit S^-1 in registers, the blocks of Hs^-1 in LDS)" if ncomp > 0 and not admm_on else
+                                "dual active-set kernels (8/32 lanes per instance, explicit S^-1 in registers, Hs^-1 in LDS)"),
+                  "split_components": ncomp, "keep_state": args.keep_state,
+                  ("with_state_ms" if not args.keep_state else "without_state_ms"): other_ms,
                   "admm_iters_mean": iters_mean, "admm_iters_max": iters_max,
                   "polish_steps_mean": psteps_mean, "polish_steps_max": psteps_max,
                   "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": self.setup_ms,
@@ -420,7 +504,7 @@ class BoxWorkload:
                   "collectives_in_step": "all_reduce(MAX) of the worst status of every step (0 = all solved), 8 steps per collective" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend, "allgather_ms": allgather_ms, "shard_sweep_ms": sweep,
                   "two_handles_two_streams_ms_per_solve": overlap_ms,
-                  "hbm_GBps_compulsory": B * (8 * prob["nx"] + 8 * n + 16 + 4 * 8 * n) / (both_ms * 1e-3) / 1e9}
+                  "hbm_GBps_compulsory": compulsory / (both_ms * 1e-3) / 1e9}
         return config, roofline
 
     def cpu_baseline(self):

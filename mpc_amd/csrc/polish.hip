@@ -553,45 +553,22 @@ int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
 // cascade could not finish (need != 0: more active rows than the last pass holds, or a numerical guard) is queued and
 // solved again as a whole, from the empty set, by the any-size kernel -- p is the UNSPLIT parameter set plus sp_C / sp_part /
 // sp_steps.
-__global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const int* need, int* redo, int* redo_count) {
+__global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const int* need, const double* c0, int* redo, int* redo_count,
+                                                           int* zero, int nzero) {
+    // the counter block of the NEXT solve (the two blocks alternate, split.hip): no memset in front of every solve
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
     const int inst = blockIdx.x * 256 + threadIdx.x, C = p.sp_C;
     if (inst >= p.B) return;
-    const int nx = p.nx, nx1 = nx + 1;
-    const double* xi = p.x0 + (size_t)inst * nx;
-    // every load of the lane first (they are independent; one after the other each is a trip to HBM)
-    constexpr int XM = 16, CM = 8;
-    double xv[XM], pv[CM]; int nv[CM], sv[CM];
+    constexpr int CM = 8;
+    double pv[CM]; int nv[CM], sv[CM];
+    double o = c0[inst];        // the unconstrained part of the objective, 1/2 [x0;1]' Cq [x0;1] (split_key_kernel)
 #pragma unroll
-    for (int b = 0; b < XM; ++b) xv[b] = b < nx ? xi[b] : 0.0;
-#pragma unroll
-    for (int c = 0; c < CM; ++c) {
+    for (int c = 0; c < CM; ++c) {      // every load of the lane first: they are independent, and each is a trip to memory
         const bool in = c < C;
         nv[c] = in ? need[(size_t)inst * C + c] : 0;
         pv[c] = in ? p.sp_part[(size_t)inst * C + c] : 0.0;
         sv[c] = in ? p.sp_steps[(size_t)inst * C + c] : 0;
     }
-    // the unconstrained part of the objective, 1/2 qs'x_unc = 1/2 [x0;1]' Cq [x0;1], once per instance
-    double o = 0.0;
-    if (nx <= XM) {
-        for (int a = 0; a < nx1; ++a) {
-            const double* cr = p.Cq + (size_t)a * nx1;
-            double sa = cr[nx];
-#pragma unroll
-            for (int b = 0; b < XM; ++b) if (b < nx) sa += cr[b] * xv[b];
-            double va = 1.0;
-#pragma unroll
-            for (int b = 0; b < XM; ++b) if (b == a) va = xv[b];
-            o += sa * va;
-        }
-    } else {
-        for (int a = 0; a < nx1; ++a) {
-            const double* cr = p.Cq + (size_t)a * nx1;
-            double sa = cr[nx];
-            for (int b = 0; b < nx; ++b) sa += cr[b] * xi[b];
-            o += sa * (a < nx ? xi[a] : 1.0);
-        }
-    }
-    o *= 0.5;
     bool ok = true; int steps = 0;
 #pragma unroll
     for (int c = 0; c < CM; ++c) { ok = ok && nv[c] == 0; o += pv[c]; steps += sv[c]; }
@@ -604,8 +581,9 @@ __global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const in
     if (p.info.polish_steps) p.info.polish_steps[inst] = steps;
 }
 
-int launch_split_finish(const PolParams& pin, const int* need, int* redo, int* redo_count, hipStream_t st) {
-    hipLaunchKernelGGL(split_finish_kernel, dim3(ceil_div(pin.B, 256)), dim3(256), 0, st, pin, need, redo, redo_count);
+int launch_split_finish(const PolParams& pin, const int* need, const double* c0, int* redo, int* redo_count, int* zero, int nzero,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(split_finish_kernel, dim3(ceil_div(pin.B, 256)), dim3(256), 0, st, pin, need, c0, redo, redo_count, zero, nzero);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
     PolParams p = pin;

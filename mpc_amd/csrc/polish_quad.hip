@@ -1237,8 +1237,10 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
 //     multipliers) are written here, its part of the objective is zero, and it never reaches the active-set kernels;
 //   * the others are put into the bucket of their number of violated rows (what predicts their work), largest first, as
 //     cold_key_kernel does for whole instances.
+//   * the unconstrained part of the instance's objective, 1/2 [x0;1]' Cq [x0;1], comes off the same tiles (X Cq' on MFMA, then a
+//     dot product with [x0;1] across the 16 lanes of a row) and is left in c0out for split_finish_kernel.
 // p is the UNSPLIT parameter set (map, bounds, scaling of the whole problem; B instances) plus sp_C, sp_part, sp_steps.
-__global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* rowmap, int* need, int* bins, int* seg) {
+__global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* rowmap, int* need, int* bins, int* seg, double* c0out) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int hist[NBIN];
     __shared__ int base[NBIN];
@@ -1303,6 +1305,28 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
         for (int t = 0; t < 8; ++t)
             if (t < NT) acc[t] = mfma_f64(xv, sKu[k * NQ + 16 * t + col], acc[t]);
     }
+    {   // 1/2 v' Cq v, v = [x0; 1]: D[i][a] = sum_k X[i][k] Cq[a][k] for 16 values of a at a time, times v_i[a], summed over a
+        const int nx1 = nx + 1;
+        double cr[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int ta = 0; 16 * ta < nx1; ++ta) {
+            const int a = 16 * ta + col;
+            d4 cacc = d4{0, 0, 0, 0};
+            for (int s = 0; s < KS; ++s) {
+                const int k = 4 * s + kq;
+                const double bq = (a < nx1 && k < nx1) ? p.Cq[(size_t)a * nx1 + k] : 0.0;
+                cacc = mfma_f64(xrow[k], bq, cacc);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) cr[r] += cacc[r] * (a < nx1 ? sX[(size_t)(wave * 16 + kq + 4 * r) * XS + a] : 0.0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) cr[r] += __shfl_xor(cr[r], off);
+            const int inst = blockIdx.x * 64 + wave * 16 + kq + 4 * r;
+            if (col == 0 && inst < p.B) c0out[inst] = 0.5 * cr[r];
+        }
+    }
     // violated rows per (instance, component): 8-bit fields of one 64-bit word per instance (at most 8 components, 128 rows)
     unsigned long long cnt[4] = {0ull, 0ull, 0ull, 0ull};
 #pragma unroll
@@ -1366,12 +1390,12 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
         if (mk[u]) seg[(size_t)mk[u] * ((size_t)p.B * C) + base[mk[u]] + ml[u]] = ms[u];
 }
 
-int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, hipStream_t st) {
+int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, double* c0out, hipStream_t st) {
     if (p.sp_C > 8 || p.n > 128) return -1;
     const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
     const size_t kl = ((size_t)kp * nq + 3 * nq + 64 * (size_t)(kp + 1)) * sizeof(double) + nq * sizeof(int);
     if (kl > 64 * 1024) return -1;
-    hipLaunchKernelGGL(split_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, rowmap, need, bins, seg);
+    hipLaunchKernelGGL(split_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, rowmap, need, bins, seg, c0out);
     return (int)hipGetLastError();
 }
 

@@ -25,7 +25,9 @@
 #include <vector>
 #include <cmath>
 
-int launch_split_finish(const PolParams& p, const int* need, int* redo, int* redo_count, hipStream_t st);   // polish.hip: per-instance record, whole-instance redo
+// polish.hip: per-instance record, whole-instance redo, and the next solve's counters zeroed
+int launch_split_finish(const PolParams& p, const int* need, const double* c0, int* redo, int* redo_count, int* zero, int nzero,
+                        hipStream_t st);
 
 namespace {
 
@@ -89,13 +91,17 @@ int sp_alloc(mpcqp_handle h, T** p, size_t count) {
 }
 
 // int workspace for BC sub-instances of B instances:
-//   need[BC] | queue 1 [BC] | queue 2 [BC] | steps[BC] | counters (96 + 32 x 32) | buckets [32][BC]
-struct SplitWs { int *need, *q1, *q2, *steps, *counters, *seg; };
+//   need[BC] | queue 1 [BC] | queue 2 [BC] | steps[BC] | two counter blocks (96 + 32 x 32 each) | buckets [32][BC]
+// The counter blocks alternate from solve to solve: the last kernel of a solve zeroes the block of the next one.
+constexpr int NCNT = 96 + NBIN * BIN_STRIDE;
+struct SplitWs { int *need, *q1, *q2, *steps, *counters, *other, *seg; };
 SplitWs split_ws(mpcqp_handle h) {
     const size_t BC = h->sp_bcap;
     SplitWs w;
     w.need = h->sp_iws; w.q1 = w.need + BC; w.q2 = w.q1 + BC; w.steps = w.q2 + BC;
-    w.counters = w.steps + BC; w.seg = w.counters + 96 + NBIN * BIN_STRIDE;
+    int* blocks = w.steps + BC;
+    w.counters = blocks + (h->sp_flip ? NCNT : 0); w.other = blocks + (h->sp_flip ? 0 : NCNT);
+    w.seg = blocks + 2 * NCNT;
     return w;
 }
 
@@ -103,8 +109,9 @@ int split_ensure_batch(mpcqp_handle h, int B) {
     const int need = ceil_div(B, 64) * 64 * h->sp_C;
     if (need <= h->sp_bcap) return MPCQP_OK;
     const size_t BC = need;
-    int rc = sp_alloc(h, &h->sp_iws, 4 * BC + 96 + NBIN * BIN_STRIDE + (size_t)NBIN * BC);
-    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_part, BC);
+    int rc = sp_alloc(h, &h->sp_iws, 4 * BC + 2 * NCNT + (size_t)NBIN * BC);        // zeroed: both counter blocks start clean
+    if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_part, BC + BC / h->sp_C);              // parts per sub-instance | c0 per instance
+    h->sp_flip = 0;
     // hand-over records (polish_quad.hip): K*K + 4K + 2 doubles for K slots; sized for half (a quarter) of the sub-instances
     // outgrowing 8 (16) slots -- beyond that a sub-instance starts its next pass from the empty set
     h->sp_cap1 = (int)(BC / 2); h->sp_cap2 = (int)(BC / 4);
@@ -199,8 +206,14 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     int rc = split_ensure_batch(h, Binst);
     if (rc != MPCQP_OK) return (int)hipErrorOutOfMemory;
     const SplitWs w = split_ws(h);
-    hipError_t e = hipMemsetAsync(w.counters, 0, (96 + NBIN * BIN_STRIDE) * sizeof(int), st);
-    if (e != hipSuccess) return (int)e;
+    double* c0 = h->sp_part + h->sp_bcap;
+    // leaving early (a failed launch; the timing modes of bench.py that stop before the finish kernel): the next solve's
+    // counter block is zeroed here instead of by that kernel
+    auto leave = [&](int code) {
+        (void)hipMemsetAsync(w.other, 0, NCNT * sizeof(int), st);
+        h->sp_flip ^= 1;
+        return code;
+    };
     PolParams p = pin;
     p.sp_C = C; p.sp_ld = h->sp_ld; p.sp_n = pin.n; p.sp_NP = pin.NP; p.sp_perm = h->sp_perm; p.sp_img = h->sp_img;
     p.sp_part = h->sp_part; p.sp_steps = w.steps;
@@ -212,31 +225,37 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     {
         PolParams k = pin;
         k.sp_C = C; k.sp_part = h->sp_part; k.sp_steps = w.steps;
-        rc = launch_split_key(k, h->sp_rowmap, w.need, w.counters + 96, w.seg, st);
-        if (rc != 0) return rc;
+        rc = launch_split_key(k, h->sp_rowmap, w.need, w.counters + 96, w.seg, c0, st);
+        if (rc != 0) return leave(rc);
     }
-    if (stop_after == 2) return 0;
+    if (stop_after == 2) return leave(0);
     // 8 slots -> 16 -> 32, each pass taking the queue (and the working states) the one before left.
     // (Measured and dropped: components that violate 6 rows or more -- they outgrow 8 slots almost surely -- started in the 16-slot
     // pass on a second stream BESIDE the first pass: the fork / join through events cost ~40 us of gaps per solve, more than the
     // 35 us the queue-fed 16-slot pass lasts.)
+    // A small batch (one round of workgroups in any pass) lasts as long as its longest chain of dependent steps, whatever
+    // the launch holds: it starts in the 16-slot pass -- one launch and one hand-over fewer for the components that outgrow 8
+    const bool small = (long)Binst * C <= h->sp_small;
     PolParams a = p;
     a.seg = w.seg; a.seg_counts = w.counters + 96; a.seg_lo = 1; a.seg_hi = NBIN - 1;
-    a.qin = nullptr; a.qin_count = nullptr; a.qout = w.q1; a.qout_count = w.counters;
-    a.hand_in = nullptr; a.hand_out = h->sp_hb1; a.hand_out_cap = h->sp_cap1;
-    rc = launch_oct_split(a, 8, st);
-    if (rc != 0) return rc;
-    if (stop_after == 1) return 0;      // timing of the first pass alone (bench.py): the batch is left partly solved
-    PolParams b = p;
-    b.qin = w.q1; b.qin_count = w.counters; b.qout = w.q2; b.qout_count = w.counters + 1;
-    b.hand_in = h->sp_hb1; b.hand_out = h->sp_hb2; b.hand_out_cap = h->sp_cap2;
-    rc = launch_oct_split(b, 16, st);
-    if (rc != 0) return rc;
+    a.qin = nullptr; a.qin_count = nullptr; a.hand_in = nullptr;
+    if (small) { a.qout = w.q2; a.qout_count = w.counters + 1; a.hand_out = h->sp_hb2; a.hand_out_cap = h->sp_cap2; }
+    else { a.qout = w.q1; a.qout_count = w.counters; a.hand_out = h->sp_hb1; a.hand_out_cap = h->sp_cap1; }
+    rc = launch_oct_split(a, small ? 16 : 8, st);
+    if (rc != 0) return leave(rc);
+    if (stop_after == 1) return leave(0);      // timing of the first pass alone (bench.py): the batch is left partly solved
+    if (!small) {
+        PolParams b = p;
+        b.qin = w.q1; b.qin_count = w.counters; b.qout = w.q2; b.qout_count = w.counters + 1;
+        b.hand_in = h->sp_hb1; b.hand_out = h->sp_hb2; b.hand_out_cap = h->sp_cap2;
+        rc = launch_oct_split(b, 16, st);
+        if (rc != 0) return leave(rc);
+    }
     PolParams c = p;
     c.qin = w.q2; c.qin_count = w.counters + 1; c.qout = nullptr; c.qout_count = nullptr;
     c.hand_in = h->sp_hb2; c.hand_out = nullptr; c.hand_out_cap = 0;
     rc = launch_oct_split(c, 32, st);
-    if (rc != 0) return rc;
+    if (rc != 0) return leave(rc);
     // the instances' records from their components' parts; an instance with a component the cascade could not finish (more than
     // 32 active rows in a component of more than 32 rows, or a numerical guard) is solved again as a whole, unsplit, from the
     // empty set, by the any-size kernel
@@ -244,5 +263,8 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     f.pass = 1; f.qin = nullptr; f.qin_count = nullptr; f.qout = nullptr; f.qout_count = nullptr;
     f.hand_in = nullptr; f.hand_out = nullptr; f.hand_zw = 0; f.seg = nullptr;
     f.sp_C = C; f.sp_part = h->sp_part; f.sp_steps = w.steps;
-    return launch_split_finish(f, w.need, w.q1, w.counters + 2, st);      // queue 1 is free again
+    rc = launch_split_finish(f, w.need, c0, w.q1, w.counters + 2, w.other, NCNT, st);      // queue 1 is free again
+    if (rc != 0) return leave(rc);
+    h->sp_flip ^= 1;
+    return 0;
 }
