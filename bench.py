@@ -98,9 +98,31 @@ def needs_launch(args, environ):
     return args.gpus > 1 and "WORLD_SIZE" not in environ
 
 
+def visible_gpus(environ, sysfs="/sys/class/kfd/kfd/topology/nodes"):
+    """GPUs the ranks will see, WITHOUT touching the HIP runtime (the launcher must stay a process that never initialised
+    the GPU; torch.cuda.device_count() can fall back to hipGetDeviceCount): the visibility variables if set, else the KFD
+    topology (nodes with SIMDs are GPUs); None if neither can be read."""
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = environ.get(var)
+        if v is not None:
+            return len([t for t in v.split(",") if t.strip() != ""])
+    try:
+        n = 0
+        for node in os.listdir(sysfs):
+            with open(os.path.join(sysfs, node, "properties")) as f:
+                for line in f:
+                    k, _, val = line.partition(" ")
+                    if k == "simd_count" and int(val) > 0:
+                        n += 1
+        return n
+    except (OSError, ValueError):
+        return None
+
+
 def launch(args, argv):
-    import torch            # counting devices does not initialise HIP; nothing else of torch.cuda is called here
-    ndev = torch.cuda.device_count()
+    ndev = visible_gpus(os.environ)
+    if ndev is None:
+        ndev = args.gpus            # cannot tell: assume one device per rank (RCCL); MPC_BENCH_BACKEND=gloo overrides
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     cmd = launch_command(args.gpus, argv, port)
     # children are fresh processes (never an exec of this one); stdout is inherited, so rank 0's JSON line is ours

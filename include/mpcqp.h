@@ -307,6 +307,18 @@ int mpcqp_ltv_bicycle_apply(int device_id, int batch, int N, double dt, double L
 int mpcqp_ltv_bicycle_step(int device_id, int batch, double dt, double L, const double* x, const double* u, double* x_next,
                            void* stream);
 
+/* -- multi-GPU: there are NO mpcqp_comm_* entry points, on purpose -------------------------------------------------
+ * SURVEY.md section 8(b2) sketched mpcqp_comm_init_all / mpcqp_allgather_solutions / mpcqp_allreduce_flag over a
+ * single-process ncclCommInitAll.  They are not part of this library: MPC instances are independent, so a rank never
+ * needs another rank's data to solve its shard, and the deployment model of this boundary is ONE PROCESS PER GPU
+ * (each with its own handle, created with its device_id) -- the process launcher and the two optional collectives
+ * (all-gather of U, all-reduce of the worst status) belong to the host framework that already owns the ranks:
+ * torch.distributed / RCCL in mpc_amd/distributed.py and bench.py, MPI or plain RCCL for a C or C++ caller (the
+ * buffers are ordinary device pointers: ncclAllGather(U_shard, U_all, rows * N*nu, ncclDouble, comm, stream) and
+ * ncclAllReduce(worst_status, ..., 1, ncclInt32, ncclMax, comm, stream) on the stream given to mpcqp_solve).  A second,
+ * single-process communicator inside the library would duplicate that and tie the handle to one process owning all
+ * devices.  The reference has no counterpart either way (SE3Planner.py:108-195 couples QPs only in time). */
+
 #ifdef __cplusplus
 }
 #endif

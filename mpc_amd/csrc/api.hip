@@ -41,12 +41,28 @@ int ensure_batch(mpcqp_handle h, int B) {
     TRY(dev_alloc(h, &h->it_ws, (size_t)need * (5 + 32) + 96 + 1024));   // iters | need_big | converged | queue 1 | queue 2 | counters | bucket sizes (32 x 32) | the 32 buckets of the cold-start order
     TRY(dev_alloc(h, &h->rp_ws, (size_t)need));
     TRY(dev_alloc(h, &h->rd_ws, (size_t)need));
-    TRY(dev_alloc(h, &h->hbuf1, (size_t)need * (16 * 16 + 4 * 16 + 2)));
-    TRY(dev_alloc(h, &h->hbuf2, (size_t)(need / 4) * (32 * 32 + 4 * 32 + 2)));
+    // the hand-over records of the whole-instance cascade (2.6 KB per instance) are allocated by the first solve that takes
+    // that cascade (ensure_handover): models solved component by component, one model per instance, warm-started and
+    // ADMM-first solves never touch them
+    if (h->hbuf1) { (void)hipFree(h->hbuf1); h->hbuf1 = nullptr; }
+    if (h->hbuf2) { (void)hipFree(h->hbuf2); h->hbuf2 = nullptr; }
+    h->hcap = 0;
     h->Bcap = need;
     h->has_state = false;
     return MPCQP_OK;
 }
+
+}  // namespace
+
+int ensure_handover(mpcqp_handle h) {
+    if (h->hcap >= h->Bcap) return MPCQP_OK;
+    TRY(dev_alloc(h, &h->hbuf1, (size_t)h->Bcap * (16 * 16 + 4 * 16 + 2)));
+    TRY(dev_alloc(h, &h->hbuf2, (size_t)(h->Bcap / 4) * (32 * 32 + 4 * 32 + 2)));
+    h->hcap = h->Bcap;
+    return MPCQP_OK;
+}
+
+namespace {
 
 __global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int nu) {
     // one 64-lane wave per instance; rows move forward by one stage (nu rows), the last stage repeats
@@ -307,7 +323,8 @@ int mpcqp_get(mpcqp_handle h, int which, int model, double* out, long out_len, v
         case 2: src = h->f0 + model * n; len = n; break;
         case 3:
             if (!h->assembled) { h->err = "get: assemble first"; return MPCQP_ESTATE; }
-            if (!h->gam_valid) { HIPCHK(h, hipSetDevice(h->dev)); TRY(launch_assemble(h, static_cast<hipStream_t>(stream), true)); }
+            // (one model per instance, structured assembly: the rollout phase alone -- H, F, f0 keep the bits that were factored)
+            if (!h->gam_valid) { HIPCHK(h, hipSetDevice(h->dev)); TRY(launch_assemble(h, static_cast<hipStream_t>(stream), true, true)); }
             src = h->Gam + model * p * n; len = p * n; break;
         case 4: src = h->Phi + model * p * nx; len = p * nx; break;
         case 5: src = h->Hs + (h->dims.n_models > 1 ? model * n * n : 0); len = n * n; break;

@@ -497,7 +497,9 @@ static int launch_assemble_wave(mpcqp_handle h, hipStream_t st) {
 }
 
 // with_gamma: the caller needs Gamma / Qbar Gamma in memory (state or polytopic rows, mpcqp_get of Gamma)
-int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma) {
+// gamma_only (one model per instance): only the rollout phase -- Gamma, Qbar Gamma, Phi -- so that H, F, f0 keep the bits the
+// factorisation was made from (an introspection call must not change what a later solve or mpcqp_get(H) sees)
+int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma, bool gamma_only) {
     if (!with_gamma) {
         const int rc = launch_assemble_wave(h, st);
         if (rc >= 0) { if (rc == MPCQP_OK) h->gam_valid = false; return rc; }
@@ -521,7 +523,7 @@ int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma) {
     hipError_t e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&assemble_kernel), lds);
     if (e != hipSuccess) { h->err = hipGetErrorString(e); return MPCQP_EHIP; }
     if (h->dims.n_models > 1) {
-        a.phases = 3;
+        a.phases = gamma_only ? 1 : 3;
         hipLaunchKernelGGL(assemble_kernel, dim3(h->dims.n_models), dim3(256), lds, st, a);
     } else {
         // one shared model: the rollout over up to 32 workgroups (one or more column tiles each), then the tiles of H and F

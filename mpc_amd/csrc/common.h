@@ -55,6 +55,7 @@ struct mpcqp_handle_s {
     int *it_ws = nullptr;                  // [6 Bcap + 96]: iters | need_big | converged | polish queue 1 | queue 2 | counters, buckets (96) | cold-start order
     double *rp_ws = nullptr, *rd_ws = nullptr;
     double *hbuf1 = nullptr, *hbuf2 = nullptr;   // hand-over of the working state between active-set passes: [Bcap][16*16+66], [Bcap/4][32*32+130]
+    int hcap = 0;                                // batch capacity they were allocated for (0: not yet -- ensure_handover, api.hip)
     // general-constraint path (general.hip): state-box / polytopic rows, or N*nu > 128
     const double *g_xmin = nullptr, *g_xmax = nullptr, *g_C = nullptr, *g_cmin = nullptr, *g_cmax = nullptr;   // caller-owned
     int g_nc = 0;
@@ -97,7 +98,7 @@ struct mpcqp_handle_s {
 hipError_t ensure_dyn_lds(int device, const void* kernel, size_t bytes);
 
 // ---- launchers implemented in the kernel translation units ----------------------
-int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma);
+int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma, bool gamma_only = false);
 int launch_factor(mpcqp_handle h, double rho, hipStream_t st);
 int launch_factor_batch(mpcqp_handle h, hipStream_t st, bool probe);
 int launch_admm_shared_box(mpcqp_handle h, const double* x0, int B, const mpcqp_solve_opts& o, hipStream_t st);
@@ -109,6 +110,7 @@ bool admm_shared_box_supported(int NT, int S);
 long blocked_inverse_scratch(int n);
 int blocked_spd_inverse(double* W, int n, double* Lout, double* Tt, double* blk, double* X, int* flag, int flag_bits,
                         hipStream_t st);
+int ensure_handover(mpcqp_handle h);      // api.hip: the whole-instance cascade's hand-over records, on first use
 int factor_general(mpcqp_handle h, hipStream_t st);
 // split.hip: look for independent components in the factored shared model (synchronises `st`); free its buffers
 int split_setup(mpcqp_handle h, hipStream_t st);

@@ -29,17 +29,48 @@ struct RowsParams {
     const int* pos;                             // nullptr: every row at its own index; else row -> kept index or -1 (dropped)
     int m;                                      // rows kept (with pos)
     long bnd_stride;                            // one model per instance (blockIdx.z): doubles between the input bounds of models
-    int bounds_only;                            // 1: write only h (pass 1: which rows have a finite bound)
+    int mdl0;                                   // first model of this launch (grid.z holds at most 65,535: launches go by chunks)
 };
+
+// the bound of row `row` of [I; -I; Gamma; -Gamma; C Gamma; -C Gamma] U <= bound - E x0 for model `mdl` (only the input
+// bounds can differ between models)
+__device__ __forceinline__ double row_bound(const RowsParams& r, int row, size_t mdl) {
+    const int n = r.n, p = r.p;
+    if (row < 2 * n) {
+        const bool up = row < n;
+        const int i = up ? row : row - n;
+        const int j = r.per_stage ? i : (i % r.nu);
+        return up ? r.umax[mdl * r.bnd_stride + j] : -r.umin[mdl * r.bnd_stride + j];
+    }
+    int rr = row - 2 * n;
+    const int xrows = r.xbox ? 2 * p : 0;
+    if (rr < xrows) { const bool up = rr < p; const int i = up ? rr : rr - p; return up ? r.xmax[i] : -r.xmin[i]; }
+    rr -= xrows;
+    const int half = r.N * r.nc;
+    const bool up = rr < half;
+    const int i = up ? rr : rr - half;
+    return up ? r.cmax[i] : -r.cmin[i];
+}
+
+// pass 1: keep[row] = 1 if ANY model has a finite bound on the row (a row open in model 0 but bounded in model b must
+// stay; where it is open, its infinite bound never binds)
+__global__ __launch_bounds__(256) void finite_rows_kernel(RowsParams r, int nm, int* keep) {
+    const int row = blockIdx.x;
+    if (row >= r.mfull) return;
+    const int nmr = (row < 2 * r.n && r.bnd_stride) ? nm : 1;      // rows beyond the input box have one bound for all models
+    bool any = false;
+    for (int mdl = blockIdx.y * 256 + threadIdx.x; mdl < nmr; mdl += gridDim.y * 256) any = any || isfinite(row_bound(r, row, (size_t)mdl));
+    if (any) keep[row] = 1;
+}
 
 // one thread per (row, column of [G | E]); column 0 also writes the bound
 __global__ __launch_bounds__(256) void build_rows_kernel(RowsParams r) {
     const int row = blockIdx.x, c = blockIdx.y * 256 + threadIdx.x;
     const int n = r.n, nx = r.nx, p = r.p;
-    if (row >= r.mfull || c >= n + nx || (r.bounds_only && c != 0)) return;
+    if (row >= r.mfull || c >= n + nx) return;
     const int orow = r.pos ? r.pos[row] : row;          // where the row lands (pruned layout), -1: dropped
     if (orow < 0) return;
-    const size_t mdl = blockIdx.z;                      // model (0 for a shared model)
+    const size_t mdl = (size_t)r.mdl0 + blockIdx.z;     // model (0 for a shared model)
     const int mrows = r.pos ? r.m : r.mfull;
     r.Gam += mdl * (size_t)p * n; r.Phi += mdl * (size_t)p * nx;
     r.umin += mdl * r.bnd_stride; r.umax += mdl * r.bnd_stride;
@@ -77,12 +108,12 @@ __global__ __launch_bounds__(256) void build_rows_kernel(RowsParams r) {
             bound = up ? r.cmax[i] : -r.cmin[i];
         }
     }
-    if (!r.bounds_only) { if (isG) r.G[(size_t)orow * n + cc] = val; else r.E[(size_t)orow * nx + cc] = val; }
+    if (isG) r.G[(size_t)orow * n + cc] = val; else r.E[(size_t)orow * nx + cc] = val;
     if (c == 0) r.h[orow] = bound;
 }
 
-// pos[i] = rows with a finite bound before row i; *count = their number (one workgroup, chunked scan)
-__global__ __launch_bounds__(1024) void finite_scan_kernel(const double* hfull, int rows, int* pos, int* count) {
+// pos[i] = kept rows before row i (-1: dropped); *count = their number (one workgroup, chunked scan)
+__global__ __launch_bounds__(1024) void finite_scan_kernel(const int* keep, int rows, int* pos, int* count) {
     __shared__ int part[1024];
     __shared__ int carry;
     const int tid = threadIdx.x;
@@ -90,7 +121,7 @@ __global__ __launch_bounds__(1024) void finite_scan_kernel(const double* hfull, 
     __syncthreads();
     for (int base = 0; base < rows; base += 1024) {
         const int i = base + tid;
-        const int k = (i < rows && isfinite(hfull[i])) ? 1 : 0;
+        const int k = (i < rows && keep[i]) ? 1 : 0;
         part[tid] = k;
         __syncthreads();
         for (int s = 1; s < 1024; s <<= 1) {
@@ -132,8 +163,8 @@ __global__ void general_info_kernel(const int* st, const int* it, int B, mpcqp_i
 
 // one model per instance: q_b = F_b x0_b + f0_b (n), h_b = h0_b - E_b x0_b (m)
 __global__ __launch_bounds__(256) void affine_per_model_kernel(const double* x0, const double* F, const double* f0, const double* E,
-                                                               const double* h0, double* q, double* hh, int n, int m, int nx) {
-    const size_t b = blockIdx.y;
+                                                               const double* h0, double* q, double* hh, int n, int m, int nx, int b0) {
+    const size_t b = (size_t)b0 + blockIdx.y;
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= n + m) return;
     const double* xb = x0 + b * nx;
@@ -181,21 +212,22 @@ int factor_general(mpcqp_handle h, hipStream_t st) {
     general_free(h);
     // the rows are built from Gamma: assemble it if the last assembly took the route that skips it
     if (!h->gam_valid && (xbox || nc > 0)) { const int ra = launch_assemble(h, st, true); if (ra != MPCQP_OK) return ra; }
-    double* hf = nullptr; int* pos = nullptr;
-    auto cleanup = [&]() { for (void* q : {(void*)hf, (void*)pos}) if (q) (void)hipFree(q); };
-    int rc = grow(h, &hf, (size_t)mfull);
+    int* keep = nullptr; int* pos = nullptr;
+    auto cleanup = [&]() { for (void* q : {(void*)keep, (void*)pos}) if (q) (void)hipFree(q); };
+    int rc = grow(h, &keep, (size_t)mfull);
     if (rc == MPCQP_OK) rc = grow(h, &pos, (size_t)mfull + 1);
+    if (rc == MPCQP_OK && hipMemsetAsync(keep, 0, (size_t)mfull * sizeof(int), st) != hipSuccess) rc = MPCQP_EHIP;
     if (rc != MPCQP_OK) { cleanup(); return rc; }
     RowsParams r;
     r.Gam = h->Gam; r.Phi = h->Phi; r.umin = h->umin; r.umax = h->umax; r.per_stage = h->per_stage;
     r.xmin = h->g_xmin; r.xmax = h->g_xmax; r.C = h->g_C; r.cmin = h->g_cmin; r.cmax = h->g_cmax; r.nc = nc;
     r.n = n; r.nx = nx; r.nu = h->dims.nu; r.N = N; r.p = p; r.xbox = xbox ? 1 : 0; r.mfull = (int)mfull;
-    r.bnd_stride = h->bnd_stride;
-    // pass 1: the bounds alone (column 0 of model 0) decide which rows exist -- rows with an infinite bound constrain nothing
-    // (one model per instance: the pattern of model 0 stands for all; a kept row whose own bound is infinite never binds)
-    r.G = nullptr; r.E = nullptr; r.h = hf; r.pos = nullptr; r.m = 0; r.bounds_only = 1;
-    hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)mfull, 1, 1), dim3(256), 0, st, r);
-    hipLaunchKernelGGL(finite_scan_kernel, dim3(1), dim3(1024), 0, st, hf, (int)mfull, pos, pos + mfull);
+    r.bnd_stride = h->bnd_stride; r.mdl0 = 0;
+    // pass 1: the bounds alone decide which rows exist -- a row whose bound is infinite in EVERY model constrains nothing
+    // (one model per instance: a kept row whose own bound is infinite never binds in that model)
+    r.G = nullptr; r.E = nullptr; r.h = nullptr; r.pos = nullptr; r.m = 0;
+    hipLaunchKernelGGL(finite_rows_kernel, dim3((unsigned)mfull, (unsigned)std::min(64, ceil_div(nm, 256))), dim3(256), 0, st, r, nm, keep);
+    hipLaunchKernelGGL(finite_scan_kernel, dim3(1), dim3(1024), 0, st, keep, (int)mfull, pos, pos + mfull);
     int m = 0;
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipMemcpyAsync(&m, pos + mfull, sizeof(int), hipMemcpyDeviceToHost, st);
@@ -207,8 +239,11 @@ int factor_general(mpcqp_handle h, hipStream_t st) {
     if (rc == MPCQP_OK) rc = grow(h, &h->gh0, (size_t)nm * m);
     if (rc != MPCQP_OK) { cleanup(); return rc; }
     // pass 2: the kept rows of every model, written at their pruned positions
-    r.G = h->gG; r.E = h->gE; r.h = h->gh0; r.pos = pos; r.m = m; r.bounds_only = 0;
-    hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)mfull, ceil_div(n + nx, 256), (unsigned)nm), dim3(256), 0, st, r);
+    r.G = h->gG; r.E = h->gE; r.h = h->gh0; r.pos = pos; r.m = m;
+    for (int m0 = 0; m0 < nm; m0 += 65535) {           // grid.z holds at most 65,535 models per launch
+        r.mdl0 = m0;
+        hipLaunchKernelGGL(build_rows_kernel, dim3((unsigned)mfull, ceil_div(n + nx, 256), (unsigned)std::min(65535, nm - m0)), dim3(256), 0, st, r);
+    }
     e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     cleanup();
@@ -254,8 +289,9 @@ int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcq
             TRYG(grow(h, &h->g_diws, (size_t)B * ni));
             h->g_dcap = B;
         }
-        hipLaunchKernelGGL(affine_per_model_kernel, dim3(ceil_div(n + m, 256), (unsigned)B), dim3(256), 0, st, x0, h->F, h->f0, h->gE,
-                           h->gh0, h->g_q, h->g_hh, n, m, nx);
+        for (int b0 = 0; b0 < B; b0 += 65535)           // grid.y holds at most 65,535 instances per launch
+            hipLaunchKernelGGL(affine_per_model_kernel, dim3(ceil_div(n + m, 256), (unsigned)std::min(65535, B - b0)), dim3(256), 0, st, x0,
+                               h->F, h->f0, h->gE, h->gh0, h->g_q, h->g_hh, n, m, nx, b0);
         HIPCHK(h, hipGetLastError());
         rc = mpcqp_solve_dense_opts(h->dev, B, n, m, 0, h->H, (long)n * n, h->g_q, n, h->gG, (long)m * n, h->g_hh, m, nullptr, 0,
                                     nullptr, 0, U, z, nullptr, obj, h->g_st, h->g_it, h->g_dws, h->g_diws, nullptr, st);

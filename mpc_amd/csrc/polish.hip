@@ -654,7 +654,14 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
     }
 #endif
     if (rc == 0) return MPCQP_OK;
-    if (rc < 0) rc = per_model ? -1 : launch_polish_quad(p, q1, q2, counters, st, stop_after);
+    if (rc < 0 && !per_model) {
+        if (p.cold && p.polish && p.refine == 0 && h->n <= 128) {       // the cascade hands working states from pass to pass
+            const int ra = ensure_handover(h);
+            if (ra != MPCQP_OK) return ra;
+            p.hand_buf1 = h->hbuf1; p.hand_buf2 = h->hbuf2;
+        }
+        rc = launch_polish_quad(p, q1, q2, counters, st, stop_after);
+    }
     if (rc == 0 && (o.stages & 12)) return MPCQP_OK;
 #ifdef POLISH_PROF
     if (rc == 0 && getenv("MPCQP_DEBUG_POLISH")) {

@@ -30,14 +30,45 @@ def _collective_device(t: torch.Tensor, group=None) -> torch.device:
     return torch.device("cpu")
 
 
-def allreduce_flag(ok, group=None) -> bool:
-    """True iff every rank reports True (all-reduce MIN of one int32)."""
-    t = ok if torch.is_tensor(ok) else torch.tensor([int(bool(ok))], dtype=torch.int32)
-    t = t.to(torch.int32).reshape(1).clone()
+class FlagReduction:
+    """An all-reduce of the convergence flag in flight.  Nothing here waits for the device or for the collective until
+    ``wait()`` is called: the worst status of the rank's shard is reduced ON THE DEVICE into the collective's own
+    buffer (no ``.item()`` in front of the collective), and the collective is launched with ``async_op=True``."""
+
+    def __init__(self, buf, work):
+        self._buf, self._work, self._result = buf, work, None
+
+    def wait(self) -> bool:
+        """True iff every instance of every rank was solved (status 0 everywhere)."""
+        if self._result is None:
+            if self._work is not None:
+                self._work.wait()
+            self._result = int(self._buf.item()) == 0
+        return self._result
+
+
+def allreduce_flag_async(status, group=None) -> FlagReduction:
+    """status: per-instance status codes (0 = solved) of this rank's shard, or a Python bool / 0-d tensor "all solved".
+    All-reduce MAX of the worst code (one int32, latency bound); returns at once."""
+    if torch.is_tensor(status):
+        worst = status.reshape(-1).amax().to(torch.int32).reshape(1) if status.numel() else torch.zeros(1, dtype=torch.int32, device=status.device)
+    else:
+        worst = torch.tensor([0 if bool(status) else 1], dtype=torch.int32)
+    work = None
     if dist.is_initialized() and dist.get_world_size(group) > 1:
-        t = t.to(_collective_device(t, group))          # a blocking copy when it leaves the device
-        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
-    return bool(t.item())
+        cdev = _collective_device(worst, group)
+        if cdev != worst.device:
+            worst = worst.to(cdev)                      # gloo (tests, rehearsal): a blocking copy; RCCL: stays on the device
+        work = dist.all_reduce(worst, op=dist.ReduceOp.MAX, group=group, async_op=True)
+    return FlagReduction(worst, work)
+
+
+def allreduce_flag(ok, group=None) -> bool:
+    """True iff every rank reports True (blocking form of allreduce_flag_async)."""
+    if torch.is_tensor(ok):
+        ok = (ok.reshape(-1) == 0).logical_not().to(torch.int32) if ok.dtype == torch.bool else (ok.reshape(-1) == 0).to(torch.int32)
+        return allreduce_flag_async(ok, group).wait()
+    return allreduce_flag_async(bool(ok), group).wait()
 
 
 def allgather_solutions(U_local: torch.Tensor, batch: int, group=None) -> torch.Tensor:
@@ -71,17 +102,18 @@ def allgather_solutions_on(U_local: torch.Tensor, batch: int, group=None) -> tor
     return torch.cat([buf[r * mx: r * mx + (hi - lo)] for r, (lo, hi) in enumerate(sizes)], dim=0)
 
 
-def solve_sharded(planner, x0_global, gather=True, group=None, **opts):
+def solve_sharded(planner, x0_global, gather=True, group=None, wait=True, **opts):
     """Every rank holds the same `x0_global` (B, nx) (or just its own rows if gather=False and it
     passes them directly); rank r solves rows shard_range(B, r, world) with its own `planner` and,
-    if `gather`, all ranks end up with the full U.  Returns (U, all_solved)."""
+    if `gather`, all ranks end up with the full U.  Returns (U, all_solved); with wait=False the second
+    value is the FlagReduction still in flight (``.wait()`` it when the answer is needed), and the
+    host has not synchronised with the device anywhere in the call (RCCL backend)."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     B = x0_global.shape[0]
     lo, hi = shard_range(B, rank, world)
     U = planner.solve(x0_global[lo:hi], **opts)
-    ok = bool((planner.info.status == 0).all().item())
-    all_ok = allreduce_flag(torch.tensor([int(ok)], dtype=torch.int32, device=U.device), group)
+    flag = allreduce_flag_async(planner.info.status, group)     # device-side reduction of the shard, collective in flight
     if gather:
         U = allgather_solutions(U, B, group)
-    return U, all_ok
+    return U, (flag.wait() if wait else flag)

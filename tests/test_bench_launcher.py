@@ -29,7 +29,7 @@ def test_defaults_and_launch_decision():
         b.parse_args(["--gpus", "0"])
 
 
-def test_launch_command_and_environment():
+def test_launch_command_and_environment(tmp_path):
     b = _bench()
     argv = ["--gpus", "4", "--steps", "7"]
     cmd = b.launch_command(4, argv, 29511, python="py")
@@ -41,6 +41,18 @@ def test_launch_command_and_environment():
     assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "MPC_BENCH_BACKEND" not in env      # enough GPUs: RCCL
     assert b.launch_env(2, 1, {})["MPC_BENCH_BACKEND"] == "gloo"                           # one-GPU box: rehearsal
     assert b.launch_env(2, 1, {"MPC_BENCH_BACKEND": "nccl"})["MPC_BENCH_BACKEND"] == "nccl"
+    # the launcher counts GPUs without the HIP runtime: visibility variables first, then the KFD topology
+    assert b.visible_gpus({"HIP_VISIBLE_DEVICES": "0,3"}) == 2 and b.visible_gpus({"ROCR_VISIBLE_DEVICES": ""}) == 0
+    top = tmp_path / "nodes"
+    for i, simd in enumerate((0, 1024, 1024)):                  # node 0 is the CPU
+        (top / str(i)).mkdir(parents=True)
+        (top / str(i) / "properties").write_text(f"cpu_cores_count {8 if i == 0 else 0}\nsimd_count {simd}\n")
+    assert b.visible_gpus({}, sysfs=str(top)) == 2
+    assert b.visible_gpus({}, sysfs=str(tmp_path / "missing")) is None
+    import ast
+    src = open(b.__file__).read()
+    fn = next(n for n in ast.walk(ast.parse(src)) if isinstance(n, ast.FunctionDef) and n.name == "launch")
+    assert "torch" not in ast.unparse(fn)                       # no torch (hence no HIP) in the launcher process
 
 
 def test_launcher_starts_fresh_ranks_and_relays_rank0(tmp_path):

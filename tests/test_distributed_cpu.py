@@ -52,6 +52,12 @@ def _worker(rank, world, port, B, q):
         lo, hi = shard_range(B, rank, world)
         good = good and U3.shape[0] == hi - lo
         good = good and allreduce_flag(True) is True
+        # the asynchronous form: nothing is waited for until .wait()
+        from mpc_amd.distributed import allreduce_flag_async
+        U4, fl = solve_sharded(_FakePlanner(fail=(rank == 0)), x0, wait=False)
+        good = good and hasattr(fl, "wait") and fl.wait() is False and fl.wait() is False
+        good = good and allreduce_flag_async(torch.zeros(5, dtype=torch.int32)).wait() is True
+        good = good and allreduce_flag(torch.tensor([0, 0, 3], dtype=torch.int32)) is False
         q.put((rank, bool(good)))
     finally:
         dist.destroy_process_group()

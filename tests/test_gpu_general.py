@@ -169,6 +169,47 @@ def test_state_rows_with_one_model_per_instance_match_oracle():
     assert nopt >= 3
 
 
+def test_per_instance_bounds_that_differ_in_finiteness_are_all_kept():
+    """One model per instance with per-instance input bounds: a side that is open (+-inf) in model 0 but bounded in another
+    model must still constrain that model -- the rows to keep are decided over ALL models, not from model 0's pattern."""
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_qp
+    rng = np.random.default_rng(23)
+    nx, nu, N, nb = 3, 2, 5, 6
+    A = 0.9 * np.eye(nx) + 0.1 * rng.standard_normal((nb, N, nx, nx))
+    Bm = rng.standard_normal((nb, N, nx, nu)) * 0.6
+    Q = np.eye(nx); R = 0.1 * np.eye(nu); P = 2.0 * Q
+    u_min = np.tile(np.array([-0.3, -0.4]), (nb, N, 1)); u_max = np.tile(np.array([0.25, 0.35]), (nb, N, 1))
+    u_max[0, :, 0] = np.inf; u_min[0, :, 1] = -np.inf          # open in model 0 ...
+    u_max[3, :, 1] = np.inf                                     # ... and another pattern in model 3
+    x_min = np.array([-2.0, -np.inf, -2.0]); x_max = np.array([2.0, 2.0, np.inf])
+    x0 = rng.uniform(-1.5, 1.5, (nb, nx))
+    pl = Planner(nx, nu, N).set_model(A, Bm).set_cost(Q, R, P)
+    pl.set_constraints(u_min, u_max, x_min=x_min, x_max=x_max)
+    U = pl.solve(x0).cpu().numpy().reshape(nb, -1)
+    st = pl.info.status.cpu().numpy()
+    assert pl.general_info()["m"] == 2 * N * nu + 4 * N          # every input row (bounded in some model) + the 4 finite state sides
+    binds = 0
+    for i in range(nb):
+        prob = dict(N=N, nx=nx, nu=nu, A=A[i], B=Bm[i], Q=Q, R=R, P=P)
+        H, F, f0 = mo.condense(prob)
+        Gam, Phi = mo.rollout_matrices(A[i], Bm[i], N)
+        I = np.eye(N * nu); Z = np.zeros((N * nu, nx))
+        G = np.vstack([I, -I, Gam, -Gam]); E = np.vstack([Z, Z, Phi, -Phi])
+        h0 = np.concatenate([u_max[i].reshape(-1), -u_min[i].reshape(-1), np.tile(x_max, N), -np.tile(x_min, N)])
+        keep = np.isfinite(h0)                                  # THIS model's finite rows: the rest constrain nothing
+        G, E, h0 = G[keep], E[keep], h0[keep]
+        s = solve_qp(H, F @ x0[i] + f0, G, h0 - E @ x0[i])
+        assert s["status"] == "optimal" and st[i] == 0, i
+        assert _rel(U[i], s["x"]) <= 1e-6, i
+        Ui = U[i].reshape(N, nu)
+        assert (Ui <= u_max[i] + 1e-9).all() and (Ui >= u_min[i] - 1e-9).all(), i
+        if i > 0:
+            binds += int((np.abs(Ui[:, 0] - u_max[i][:, 0]) < 1e-9).sum())
+    assert binds > 0            # the bound that model 0 does not have does bind in the others
+
+
 @pytest.mark.parametrize("n,m,p", [(96, 40, 0), (131, 57, 3), (257, 300, 0)])
 def test_blocked_shared_setup_matches_numpy(n, m, p):
     """The multi-workgroup set-up (blocked_setup.hip: scaling kernels, blocked Cholesky and inverse on the MFMA GEMM) leaves

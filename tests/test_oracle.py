@@ -255,3 +255,36 @@ def test_brute_force_active_set_enumeration_pins_the_golden_optimum(name, golden
     # the golden active set (rows with a positive multiplier) is among the enumerated ones
     act = sorted(np.nonzero(d["z"] > 1e-9 * max(1.0, np.abs(d["z"]).max()))[0].tolist())
     assert any(sorted(S) == act for S, _, _ in found) or any(set(act) <= set(S) for S, _, _ in found)
+
+
+def test_enumeration_pins_the_first_se3_qp(golden_dir):
+    """The reference's most-called QP shape, SE3Planner.py:181,183 (18 variables, 12 box rows on them: 4,096 candidate
+    active sets): every KKT point the solver-free enumeration finds is the stored golden optimum."""
+    (P, q, G, h, A, b), d = _load(os.path.join(golden_dir, "ref_se3_first.npz"))
+    found = _enumerate_active_sets(P, q, G, h, None, None)
+    assert found, "enumeration found no KKT point"
+    xg, og = d["x"], float(d["objective"])
+    for S, x, obj in found:
+        assert abs(obj - og) <= 1e-9 * max(abs(og), 1e-300), (S, obj, og)
+        assert np.abs(x - xg).max() <= 1e-7 * max(np.abs(xg).max(), 1e-300), S
+    act = sorted(np.nonzero(d["z"] > 1e-9 * max(1.0, np.abs(d["z"]).max()))[0].tolist())
+    assert any(sorted(S) == act for S, _, _ in found) or any(set(act) <= set(S) for S, _, _ in found)
+
+
+@pytest.mark.parametrize("group,picks", [(0, (0, 5, 40)), (1, (0, 1, 2, 40))])
+def test_enumeration_pins_se3_sweep_qps(group, picks, golden_dir):
+    """The same pin on QPs from INSIDE the reference's backward sweep (SE3Planner.py:108-195): group 0 = the inequality-only
+    calls (:183), group 1 = the calls with the 3 equality rows of the foot-contact branch (:181).  The stored solutions
+    came from the oracle's interior-point restatement; the enumeration shares no code and no algorithm with it."""
+    g = np.load(os.path.join(golden_dir, "sweep_se3.npz"))
+    P, q, G, h, A, b = (g[f"g{group}_{k}"] for k in "PqGhAb")
+    for i in picks:
+        if not bool(g[f"g{group}_optimal"][i]):
+            continue
+        found = _enumerate_active_sets(P[i], q[i], G[i], h[i], A[i] if A.shape[1] else None, b[i] if A.shape[1] else None)
+        assert found, (group, i)
+        xo = g[f"g{group}_x"][i]
+        oo = 0.5 * xo @ P[i] @ xo + q[i] @ xo
+        for S, x, obj in found:
+            assert abs(obj - oo) <= 1e-9 * max(abs(oo), 1e-300), (group, i, S)
+            assert np.abs(x - xo).max() <= 1e-7 * max(np.abs(xo).max(), 1e-300), (group, i, S)
