@@ -128,7 +128,7 @@ int mpcqp_set_constraints(mpcqp_handle h, const double* u_min, const double* u_m
  * kernel (mpcqp_rows_*) or, when its m x m dual Hessian exceeds the memory limit, the general dense kernel
  * (mpcqp_dense_shared_*); mpcqp_solve then runs that kernel.  With one model per instance (n_models = batch) every
  * instance is a dense QP of its own -- its Hessian, its rows [..Gamma_b..], q_b = F_b x0_b + f0_b -- solved by the kernel
- * of mpcqp_solve_dense; the pruning pattern is that of model 0's bounds.  In this mode: no
+ * of mpcqp_solve_dense; a row is kept when its bound is finite in ANY model.  In this mode: no
  * warm start / shift, mpcqp_factor synchronises, info.lam (if given) holds (batch, m) multipliers of the kept rows
  * (m from mpcqp_general_rows; mpcqp_get 13 / 14 / 15 return G (m,n), E (m,nx), h0 (m)), status 3 = infeasible,
  * 4 = numerical failure. */
@@ -160,6 +160,17 @@ int mpcqp_set_split(mpcqp_handle h, int enable, double tol);
 /* what the last mpcqp_factor found: components (0 = not split), rows per component (the largest, padded to even);
  * row_map (host, N*nu ints, may be NULL): component of every row */
 int mpcqp_split_info(mpcqp_handle h, int* components, int* rows_per_component, int* row_map, int row_map_len);
+
+/* Recording mpcqp_solve into a HIP graph (hipStreamBeginCapture on the solve's stream).  The launch chain of a solve
+ * carries no host state -- every solve leaves its device-side counters zeroed for the next, nothing is read back -- so it
+ * can be captured and replayed, PROVIDED the device pointers the recorded kernels hold stay valid: run one eager solve of
+ * the same batch size and options first (workspaces grow, and are zero-filled with synchronous calls, on the first solve of
+ * a larger batch and on the first solve that takes a given kernel cascade), then pin the handle for as long as the graph
+ * lives.  A pinned handle (on = 1; calls nest, on = 0 undoes one) answers MPCQP_ESTATE instead of freeing or re-growing
+ * anything a graph may point into: a solve of a larger batch, a solve that needs buffers not yet allocated, mpcqp_assemble
+ * and mpcqp_factor of a shared model (new matrices under recorded kernels; the split images are re-packed).  x0, U and the info arrays are the caller's: the graph reads and
+ * writes the addresses given at capture.  (Replaces nothing in the reference, whose solves are host calls.) */
+int mpcqp_pin(mpcqp_handle h, int on);
 
 /* -- kernels ----------------------------------------------------------------------- */
 /* rollout Gamma/Phi, H = Gamma'Qbar Gamma + Rbar, F = Gamma'Qbar Phi, f0  (fp64 MFMA) */

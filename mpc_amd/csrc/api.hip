@@ -35,6 +35,7 @@ int dev_alloc(mpcqp_handle h, T** p, size_t count) {
 int ensure_batch(mpcqp_handle h, int B) {
     const int need = ceil_div(B, 64) * 64;
     if (need <= h->Bcap) return MPCQP_OK;
+    if (h->pinned) { h->err = "solve: a larger batch would re-allocate workspaces that a recorded graph points into (mpcqp_pin)"; return MPCQP_ESTATE; }
     TRY(dev_alloc(h, &h->z, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->w, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->b0ws, (size_t)need * h->NP));
@@ -56,6 +57,7 @@ int ensure_batch(mpcqp_handle h, int B) {
 
 int ensure_handover(mpcqp_handle h) {
     if (h->hcap >= h->Bcap) return MPCQP_OK;
+    if (h->pinned) { h->err = "solve: this solve needs buffers that were not allocated when the handle was pinned (mpcqp_pin)"; return MPCQP_ESTATE; }
     TRY(dev_alloc(h, &h->hbuf1, (size_t)h->Bcap * (16 * 16 + 4 * 16 + 2)));
     TRY(dev_alloc(h, &h->hbuf2, (size_t)(h->Bcap / 4) * (32 * 32 + 4 * 32 + 2)));
     h->hcap = h->Bcap;
@@ -199,6 +201,7 @@ int mpcqp_set_strides(mpcqp_handle h, long xref_stride, long uref_stride, long b
 int mpcqp_assemble(mpcqp_handle h, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->A || !h->Q) { h->err = "assemble: set_model and set_cost first"; return MPCQP_ESTATE; }
+    if (h->pinned && h->dims.n_models == 1) { h->err = "assemble: a recorded graph reads this model's matrices (mpcqp_pin): unpin first"; return MPCQP_ESTATE; }
     HIPCHK(h, hipSetDevice(h->dev));
     TRY(launch_assemble(h, static_cast<hipStream_t>(stream), h->g_xmin || h->g_C));
     h->assembled = true; h->factored = false;
@@ -209,6 +212,7 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->assembled) { h->err = "factor: assemble first"; return MPCQP_ESTATE; }
     if (!h->umin) { h->err = "factor: set_constraints first"; return MPCQP_ESTATE; }
+    if (h->pinned && h->dims.n_models == 1) { h->err = "factor: a recorded graph points into this factorisation's buffers (mpcqp_pin): unpin first"; return MPCQP_ESTATE; }
     HIPCHK(h, hipSetDevice(h->dev));
     hipStream_t st = static_cast<hipStream_t>(stream);
     h->sp_C = 0;            // the component split belongs to the factorisation it was found in (split_setup below)
@@ -268,6 +272,13 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
     if ((o.stages & 1) && h->dims.n_models == 1 && !skip_admm) TRY(launch_admm_shared_box(h, x0, batch, o, st));
     if (o.stages & 2) TRY(launch_polish_box(h, x0, batch, U, info, o, st));
     h->has_state = o.keep_state != 0; h->Blast = batch;
+    return MPCQP_OK;
+}
+
+int mpcqp_pin(mpcqp_handle h, int on) {
+    if (!h) return MPCQP_EINVAL;
+    if (!on && h->pinned == 0) { h->err = "pin: not pinned"; return MPCQP_ESTATE; }
+    h->pinned += on ? 1 : -1;
     return MPCQP_OK;
 }
 

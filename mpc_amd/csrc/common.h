@@ -76,11 +76,11 @@ struct mpcqp_handle_s {
     double *sp_Hi = nullptr, *sp_KuT = nullptr, *sp_lbs = nullptr, *sp_ubs = nullptr, *sp_d = nullptr;   // packed per component
     double* sp_img = nullptr;               // the same as ONE image in the layout of the active-set kernels' LDS (rows of sp_ld)
     int sp_small = 65536;                    // sub-instances up to which a batch starts in the 16-slot pass (split.hip)
-    int sp_flip = 0;                        // which of the two counter blocks the next solve uses (the finish kernel zeroes the other)
     int sp_bcap = 0, sp_wsC = 0, sp_wsld = 0;   // sub-instance capacity of the workspace below (grow only) and the split it was sized for
     int* sp_iws = nullptr; double* sp_part = nullptr;           // int / double workspace of the split solve (split.hip)
     double *sp_hb1 = nullptr, *sp_hb2 = nullptr; int sp_cap1 = 0, sp_cap2 = 0;   // hand-over records 8 -> 16 and 16 -> 32 slots
     bool assembled = false, factored = false, has_state = false;
+    int pinned = 0;                              // > 0: a recorded graph holds this handle's device pointers (mpcqp_pin): nothing may be freed or re-grown
     std::string err;
 };
 

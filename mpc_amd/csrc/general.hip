@@ -268,6 +268,7 @@ int factor_general(mpcqp_handle h, hipStream_t st) {
 int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st) {
     const int n = h->n, m = h->g_m, nx = h->dims.nx;
     if (B > h->g_bcap) {        // per-batch buffers (grow only; like ensure_batch this may allocate on the first larger batch)
+        if (h->pinned) { h->err = "solve: a larger batch would re-allocate workspaces that a recorded graph points into (mpcqp_pin)"; return MPCQP_ESTATE; }
         TRYG(grow(h, &h->g_z, (size_t)B * m));
         TRYG(grow(h, &h->g_obj, (size_t)B));
         TRYG(grow(h, &h->g_st, (size_t)B));

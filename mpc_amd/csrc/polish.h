@@ -62,4 +62,5 @@ int launch_polish_split(mpcqp_handle h, const PolParams& p, hipStream_t st, int 
 // polish_quad.hip: one pass of the split cascade over p.B sub-instances (or p.qin): slots = 8, 16 or 32
 int launch_oct_split(const PolParams& p, int slots, hipStream_t st);
 // polish_quad.hip: x_unc for every instance, the components it solves written out, the others bucketed by expected work
-int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, double* c0out, hipStream_t st);
+int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, double* c0out, int* redo_count,
+                     hipStream_t st);

@@ -555,8 +555,9 @@ int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
 // sp_steps.
 __global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const int* need, const double* c0, int* redo, int* redo_count,
                                                            int* zero, int nzero) {
-    // the counter block of the NEXT solve (the two blocks alternate, split.hip): no memset in front of every solve
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) zero[i] = 0;
+    // the counters of the solve that ends here, ready for the next one (no memset in front of every solve): all but the
+    // redo queue's, which the kernel after this one reads -- split_key_kernel clears that one
+    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) if (zero + i != redo_count) zero[i] = 0;
     const int inst = blockIdx.x * 256 + threadIdx.x, C = p.sp_C;
     if (inst >= p.B) return;
     constexpr int CM = 8;

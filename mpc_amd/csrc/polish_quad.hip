@@ -1240,7 +1240,8 @@ __global__ __launch_bounds__(256) void cold_key_kernel(PolParams p, int* keys, i
 //   * the unconstrained part of the instance's objective, 1/2 [x0;1]' Cq [x0;1], comes off the same tiles (X Cq' on MFMA, then a
 //     dot product with [x0;1] across the 16 lanes of a row) and is left in c0out for split_finish_kernel.
 // p is the UNSPLIT parameter set (map, bounds, scaling of the whole problem; B instances) plus sp_C, sp_part, sp_steps.
-__global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* rowmap, int* need, int* bins, int* seg, double* c0out) {
+__global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* rowmap, int* need, int* bins, int* seg, double* c0out,
+                                                        int* redo_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __shared__ int hist[NBIN];
     __shared__ int base[NBIN];
@@ -1292,6 +1293,7 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
         }
     }
     if (tid < NBIN) hist[tid] = 0;
+    if (blockIdx.x == 0 && tid == 0) *redo_count = 0;       // the one counter the last solve's finish kernel could not clear
     __syncthreads();
     const double* xrow = sX + (size_t)(wave * 16 + col) * XS;
     const int NT = NQ / 16;
@@ -1390,12 +1392,13 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
         if (mk[u]) seg[(size_t)mk[u] * ((size_t)p.B * C) + base[mk[u]] + ml[u]] = ms[u];
 }
 
-int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, double* c0out, hipStream_t st) {
+int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins, int* seg, double* c0out, int* redo_count,
+                     hipStream_t st) {
     if (p.sp_C > 8 || p.n > 128) return -1;
     const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
     const size_t kl = ((size_t)kp * nq + 3 * nq + 64 * (size_t)(kp + 1)) * sizeof(double) + nq * sizeof(int);
     if (kl > 64 * 1024) return -1;
-    hipLaunchKernelGGL(split_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, rowmap, need, bins, seg, c0out);
+    hipLaunchKernelGGL(split_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, rowmap, need, bins, seg, c0out, redo_count);
     return (int)hipGetLastError();
 }
 

@@ -91,27 +91,28 @@ int sp_alloc(mpcqp_handle h, T** p, size_t count) {
 }
 
 // int workspace for BC sub-instances of B instances:
-//   need[BC] | queue 1 [BC] | queue 2 [BC] | steps[BC] | two counter blocks (96 + 32 x 32 each) | buckets [32][BC]
-// The counter blocks alternate from solve to solve: the last kernel of a solve zeroes the block of the next one.
+//   need[BC] | queue 1 [BC] | queue 2 [BC] | steps[BC] | counters (96 + 32 x 32) | buckets [32][BC]
+// No memset in front of a solve: every solve leaves the counters zero for the next one -- the finish kernel clears all of
+// them but the redo queue's (which the kernel after it still reads), the key kernel of the next solve clears that one.  The
+// sequence of launches therefore does not depend on host state and can be replayed from a HIP graph.
 constexpr int NCNT = 96 + NBIN * BIN_STRIDE;
-struct SplitWs { int *need, *q1, *q2, *steps, *counters, *other, *seg; };
+constexpr int REDO = 2;         // counters[REDO]: length of the redo queue
+struct SplitWs { int *need, *q1, *q2, *steps, *counters, *seg; };
 SplitWs split_ws(mpcqp_handle h) {
     const size_t BC = h->sp_bcap;
     SplitWs w;
     w.need = h->sp_iws; w.q1 = w.need + BC; w.q2 = w.q1 + BC; w.steps = w.q2 + BC;
-    int* blocks = w.steps + BC;
-    w.counters = blocks + (h->sp_flip ? NCNT : 0); w.other = blocks + (h->sp_flip ? 0 : NCNT);
-    w.seg = blocks + 2 * NCNT;
+    w.counters = w.steps + BC; w.seg = w.counters + NCNT;
     return w;
 }
 
 int split_ensure_batch(mpcqp_handle h, int B) {
     const int need = ceil_div(B, 64) * 64 * h->sp_C;
     if (need <= h->sp_bcap) return MPCQP_OK;
+    if (h->pinned) { h->err = "solve: a larger batch would re-allocate workspaces that a recorded graph points into (mpcqp_pin)"; return MPCQP_ESTATE; }
     const size_t BC = need;
-    int rc = sp_alloc(h, &h->sp_iws, 4 * BC + 2 * NCNT + (size_t)NBIN * BC);        // zeroed: both counter blocks start clean
+    int rc = sp_alloc(h, &h->sp_iws, 4 * BC + NCNT + (size_t)NBIN * BC);            // zeroed: the counters start clean
     if (rc == MPCQP_OK) rc = sp_alloc(h, &h->sp_part, BC + BC / h->sp_C);              // parts per sub-instance | c0 per instance
-    h->sp_flip = 0;
     // hand-over records (polish_quad.hip): K*K + 4K + 2 doubles for K slots; sized for half (a quarter) of the sub-instances
     // outgrowing 8 (16) slots -- beyond that a sub-instance starts its next pass from the empty set
     h->sp_cap1 = (int)(BC / 2); h->sp_cap2 = (int)(BC / 4);
@@ -207,11 +208,10 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     if (rc != MPCQP_OK) return (int)hipErrorOutOfMemory;
     const SplitWs w = split_ws(h);
     double* c0 = h->sp_part + h->sp_bcap;
-    // leaving early (a failed launch; the timing modes of bench.py that stop before the finish kernel): the next solve's
-    // counter block is zeroed here instead of by that kernel
+    // leaving early (a failed launch; the timing modes of bench.py that stop before the finish kernel): the counters are
+    // zeroed here instead of by that kernel
     auto leave = [&](int code) {
-        (void)hipMemsetAsync(w.other, 0, NCNT * sizeof(int), st);
-        h->sp_flip ^= 1;
+        (void)hipMemsetAsync(w.counters, 0, NCNT * sizeof(int), st);
         return code;
     };
     PolParams p = pin;
@@ -225,7 +225,7 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     {
         PolParams k = pin;
         k.sp_C = C; k.sp_part = h->sp_part; k.sp_steps = w.steps;
-        rc = launch_split_key(k, h->sp_rowmap, w.need, w.counters + 96, w.seg, c0, st);
+        rc = launch_split_key(k, h->sp_rowmap, w.need, w.counters + 96, w.seg, c0, w.counters + REDO, st);
         if (rc != 0) return leave(rc);
     }
     if (stop_after == 2) return leave(0);
@@ -263,8 +263,7 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     f.pass = 1; f.qin = nullptr; f.qin_count = nullptr; f.qout = nullptr; f.qout_count = nullptr;
     f.hand_in = nullptr; f.hand_out = nullptr; f.hand_zw = 0; f.seg = nullptr;
     f.sp_C = C; f.sp_part = h->sp_part; f.sp_steps = w.steps;
-    rc = launch_split_finish(f, w.need, c0, w.q1, w.counters + 2, w.other, NCNT, st);      // queue 1 is free again
+    rc = launch_split_finish(f, w.need, c0, w.q1, w.counters + REDO, w.counters, NCNT, st);      // queue 1 is free again
     if (rc != 0) return leave(rc);
-    h->sp_flip ^= 1;
     return 0;
 }

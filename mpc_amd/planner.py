@@ -41,6 +41,42 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+class SolveGraph:
+    """A recorded solve (Planner.capture_solve).  ``replay(x0)`` copies the new initial states into the graph's input
+    buffer, launches the graph and returns the output buffer U (B, N, nu) -- the SAME tensor every time, overwritten by
+    the next replay; ``info`` likewise."""
+
+    def __init__(self, planner, graph, x0, U, info):
+        self.planner, self.graph, self.x0, self.U, self.info = planner, graph, x0, U, info
+        # the recorded kernels hold pointers into the handle's workspaces: until close() the library refuses (with an error,
+        # where a replay would otherwise fault) whatever would free or re-grow them -- a larger batch, a new factorisation
+        planner._check(planner._lib.mpcqp_pin(planner._h, 1))
+        self._pinned = True
+
+    def close(self):
+        """Drop the graph and let the planner re-factor / grow again."""
+        if self._pinned:
+            self._pinned = False
+            self.graph = None
+            if self.planner._h:
+                self.planner._lib.mpcqp_pin(self.planner._h, 0)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def replay(self, x0=None):
+        if self.graph is None:
+            raise RuntimeError("SolveGraph: closed")
+        if x0 is not None:
+            self.x0.copy_(x0)
+        self.graph.replay()
+        self.planner.info = self.info
+        return self.U
+
+
 class Planner:
     """Batched linear-MPC planner:  min sum 1/2|x_k-xr_k|_Q^2 + 1/2|u_k-ur_k|_R^2 + terminal P
     s.t. x_{k+1} = A_k x_k + B_k u_k, u_min <= u_k <= u_max, for a batch of x0."""
@@ -350,6 +386,34 @@ class Planner:
         self._check(self._lib.mpcqp_solve(self._h, _ptr(x0), B, _ptr(U), C.byref(ci), C.byref(o), self._stream()))
         self.info = info
         return U
+
+    def capture_solve(self, x0, want_multipliers=False, **opts):
+        """Record ``solve(x0)`` (same options) into a HIP graph: returns a SolveGraph whose ``replay(x0_new)`` runs the
+        whole launch chain of the solve with one graph launch and no host work per kernel.  Everything the chain needs
+        is in place before the capture starts -- one eager solve grows the workspaces and sets the kernels' attributes,
+        the output buffers are allocated outside the graph's pool -- and the chain itself does not depend on host state
+        (every solve leaves its device-side counters ready for the next), so the recorded launches can be replayed any
+        number of times.  The graph is tied to this batch size, these options and the current factorisation."""
+        if self._dirty:
+            self.setup()
+        x0 = _as_dev(x0, self.device)
+        if x0.dim() != 2 or x0.shape[1] != self.nx:
+            raise ValueError(f"x0: expected (B, {self.nx}), got {tuple(x0.shape)}")
+        xs = x0.clone()
+        B = xs.shape[0]
+        gm = getattr(self, "_gen_m", 0)
+        o = _lib.SolveOpts.from_buffer_copy(self.opts)
+        for k, v in opts.items():
+            if not hasattr(o, k):
+                raise TypeError(f"unknown option {k!r}")
+            setattr(o, k, v)
+        U, info, ci = self._new_outputs(B, gm, want_multipliers)
+        self._check(self._lib.mpcqp_solve(self._h, _ptr(xs), B, _ptr(U), C.byref(ci), C.byref(o), self._stream()))
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph, capture_error_mode="relaxed"):
+            self._check(self._lib.mpcqp_solve(self._h, _ptr(xs), B, _ptr(U), C.byref(ci), C.byref(o), self._stream()))
+        return SolveGraph(self, graph, xs, U, info)
 
     def _new_outputs(self, B, gm, want_multipliers):
         dev = self.device

@@ -547,3 +547,41 @@ def test_one_sided_input_bounds_match_oracle(batch, max_iter):
         assert abs(obj[i] - s["primal objective"]) <= OBJ_RTOL * max(abs(s["primal objective"]), 1e-12), i
         nbind += int((np.abs(s["x"] - ub) < 1e-9).sum() + (np.abs(s["x"] - lb) < 1e-9).sum())
     assert nbind > 0
+
+
+@pytest.mark.parametrize("cfg,batch,split", [(3, 5000, True), (3, 20000, False), (2, 3000, True)])
+def test_a_recorded_solve_replays_bit_for_bit(cfg, batch, split):
+    """Planner.capture_solve: the launch chain of one solve as a HIP graph -- component-split cascade, the whole-instance
+    cascade with its cold-start ordering, the one-pass small batch -- replayed on new x0, twice in a row, equals the eager
+    solves bit for bit (every solve leaves the device-side counters ready for the next, so the chain carries no host state)."""
+    import torch
+    from mpc_amd.configs import make_config
+    prob = make_config(cfg, batch=batch, seed=12)
+    pl = _planner(prob, split)
+    xa = torch.as_tensor(prob["x0"], device="cuda:0")
+    xb = torch.as_tensor(1.3 * prob["x0"][::-1].copy(), device="cuda:0")
+    Ua = pl.solve(xa).clone(); oa = pl.info.obj.clone()
+    Ub = pl.solve(xb).clone(); ob = pl.info.obj.clone(); sb = pl.info.polish_steps.clone()
+    g = pl.capture_solve(xa)
+    for _ in range(2):
+        U = g.replay(xb)
+        torch.cuda.synchronize()
+        assert torch.equal(U, Ub) and torch.equal(g.info.obj, ob) and torch.equal(g.info.polish_steps, sb)
+        assert int((g.info.status != 0).sum()) == 0
+        U = g.replay(xa)
+        torch.cuda.synchronize()
+        assert torch.equal(U, Ua) and torch.equal(g.info.obj, oa)
+    # eager solves after the graph still work and agree
+    assert torch.equal(pl.solve(xb), Ub)
+    # while the graph lives, whatever would free the buffers its kernels point into is an error, not a fault at the next replay
+    big = torch.cat([xa, xa, xa])[: 2 * batch + 64 * 1024]
+    with pytest.raises(RuntimeError, match="recorded graph"):
+        pl.solve(big)
+    with pytest.raises(RuntimeError, match="recorded graph"):
+        pl.set_cost(prob["Q"], 2.0 * prob["R"], prob["P"]).setup()
+    assert torch.equal(g.replay(xb), Ub)
+    g.close()
+    with pytest.raises(RuntimeError, match="closed"):
+        g.replay()
+    pl.set_cost(prob["Q"], prob["R"], prob["P"]).setup()
+    assert torch.equal(pl.solve(big)[:batch], Ua)
