@@ -67,6 +67,10 @@ def parse_args(argv=None):
                     help="configs 2/3: 1 = every solve also leaves its (z, w) warm-start state in the handle (default 0: a cold "
                          "batch solve, SURVEY.md 8(d)'s 1,072 B/solve case; the other one is reported as with_state_ms)")
     ap.add_argument("--no-split", action="store_true", help="configs 2/3: solve block-diagonal models as a whole (split off)")
+    ap.add_argument("--graph", action="store_true",
+                    help="configs 2/3: every timed step replays the recorded solve (HIP graph, Planner.capture_solve) instead of "
+                         "issuing its launches from the host; measured equal within 2 % at every batch size (graph_replay_ms, "
+                         "shard_sweep_ms.graph_replay_ms are reported either way), so the default stays the host-issued chain")
     ap.add_argument("--rho", type=float, default=None)
     args = ap.parse_args(argv)
     if args.steps is None:
@@ -354,6 +358,14 @@ class BoxWorkload:
         self.opts = {} if args.max_iter is None else {"max_iter": args.max_iter}
         pl.reuse_outputs = True
         self.U = None
+        # the solve's launch chain recorded once (Planner.capture_solve) and replayed: one graph launch per batch instead of
+        # five to seven kernel launches.  Timed beside the host-issued chain on one GPU; the timed step uses it under --graph
+        self.graph, self.graph_error = None, None
+        if args.graph or ranks.world == 1:
+            try:
+                self.graph = pl.capture_solve(self.x0, **self.opts)
+            except Exception as e:      # noqa: BLE001 -- a failed capture must not lose the line: the eager path is the same solve
+                self.graph_error = repr(e)
         self.units_per_step = self.global_batch
         self.name = {2: "configs[1]: cart-pole linearised MPC nx=4 nu=1 N=50 (n=50 box-constrained QP)",
                      3: "configs[2]: quadrotor hover MPC nx=12 nu=4 N=30 (n=120 box-constrained QP)"}[cfg]
@@ -361,7 +373,7 @@ class BoxWorkload:
     def step(self):
         # reuse_outputs: the same output buffers every step (an eager call otherwise spends more host time on small
         # allocations than the device needs for a 1/8 shard); the convergence flag is one reduction kernel
-        self.U = self.pl.solve(self.x0, **self.opts)
+        self.U = self.graph.replay() if (self.graph is not None and self.args.graph) else self.pl.solve(self.x0, **self.opts)
         if self.ranks.dist is not None:
             self.ranks.flag_allreduce(self.pl.info.status)
 
@@ -378,6 +390,7 @@ class BoxWorkload:
         admm_on = iters_max > 0
         admm_ms = timed(lambda: pl.solve(x0, stages=1, **opts), reps) if admm_on else 0.0
         both_ms = timed(lambda: pl.solve(x0, **opts), reps)
+        graph_ms = timed(self.graph.replay, reps) if self.graph is not None else None
         # the first (and longest) active-set launch alone: stages bit 2 stops after it, bit 3 after the cold-start
         # ordering kernels that run before it (diagnostic modes: queued instances stay open)
         # (the ordering kernel only runs for cold batches of more than 16,384 instances, polish_quad.hip; below that "stages=15"
@@ -404,12 +417,18 @@ class BoxWorkload:
         sweep = None
         if ranks.world == 1 and not args.no_shard_sweep and args.config == 3:
             sweep = {}
+            eager = {}
             for div in (1, 2, 4, 8):
                 b = self.global_batch // div
                 xs = self.x0_all[:b].contiguous()
                 sweep[str(b)] = timed(lambda: pl.solve(xs, **opts), reps)
+                if self.graph is not None:
+                    g = pl.capture_solve(xs, **opts)
+                    eager[str(b)] = timed(g.replay, reps)
+                    g.close()
             t1, t8 = sweep[str(self.global_batch)], sweep[str(self.global_batch // 8)]
             sweep["implied_strong_efficiency_8"] = t1 / (8.0 * t8)
+            sweep["graph_replay_ms"] = eager or None
             pl.solve(x0, **opts)
 
         # the serving pattern: two handles on two streams, solves alternating between them, so that one solve's short
@@ -523,6 +542,8 @@ class BoxWorkload:
                   "p50_batch_latency_ms": p50_ms, "p99_batch_latency_ms": p99_ms, "mean_batch_latency_ms": both_ms,
                   "admm_kernel_ms": admm_ms, "polish_kernels_ms": max(both_ms - admm_ms, 0.0),
                   "first_pass_ms": pass_a_ms, "cold_order_ms": order_ms,
+                  "step_issued_as": "graph replay (Planner.capture_solve)" if (self.graph is not None and args.graph) else "host launches",
+                  "graph_replay_ms": graph_ms, "graph_capture_error": self.graph_error,
                   "collectives_in_step": "all_reduce(MAX) of the worst status of every step (0 = all solved), 8 steps per collective" if ranks.world > 1 else "none",
                   "collective_backend": ranks.backend, "allgather_ms": allgather_ms, "shard_sweep_ms": sweep,
                   "two_handles_two_streams_ms_per_solve": overlap_ms,

@@ -359,8 +359,11 @@ struct InvStep<16> {
     static __device__ __forceinline__ void run(const double (&)[16], const double (&)[16], double (&)[16], int) {}
 };
 
-// ONE (16 NB) x (16 NB + 1) matrix in LDS holds everything: Hs -> (lower off-diagonal tiles) L_ij, (diagonal tiles) T_bb =
+// ONE n x (16 NB + 1) matrix in LDS holds everything: Hs -> (lower off-diagonal tiles) L_ij, (diagonal tiles) T_bb =
 // L_bb^-1, (upper off-diagonal tile (b, i)) T_ib' ; the tiles of Hi = T'T are accumulated in registers and overwrite it.
+// The identity padding of the last row block (rows n .. 16 NB - 1) is not stored: every step leaves it what it was (L, T and
+// Hi of the padding are the identity, its off-diagonal tiles zero), so reads of those rows are answered with the constant
+// (PADL) and writes to them dropped -- 15.7 instead of 18.8 KB per wave at n = 40, nine waves per CU instead of seven.
 template <int NB>
 __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -375,7 +378,10 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     double* __restrict__ gHi = f.Hi + m * n * n;
     double* S = reinterpret_cast<double*>(smem);
     double* sHi = S;
-    double* sd = S + (size_t)NPD * LDW;                   // d (n)
+    double* sd = S + (size_t)n * LDW;                     // d (n)
+    // rows of the LAST row block may be padding (LASTB: a compile-time fact after unrolling; the test on r is then the only cost)
+    auto PADL = [&](bool lastb, int r, int c) -> double { return (!lastb || r < n) ? S[r * LDW + c] : (r == c ? 1.0 : 0.0); };
+    auto PADS = [&](bool lastb, int r, int c, double v) { if (!lastb || r < n) S[r * LDW + c] = v; };
     double* sF = sd + n;                                  // (n, nx1) scaled [F | f0]; later two probe vectors
     const bool in = i < n;
     bool bad = false;
@@ -398,8 +404,7 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
             }
         }
     }
-    for (int r = 0; r < NPD; ++r)
-        if (i < NPD && (r >= n || i >= n)) S[r * LDW + i] = (r == i) ? 1.0 : 0.0;
+    for (int idx = i; idx < n * (NPD - n); idx += 64) { const int r = idx / (NPD - n); S[r * LDW + n + (idx - r * (NPD - n))] = 0.0; }
     wv_sync();
     if (in) {
         const double hii = S[i * LDW + i];
@@ -432,13 +437,13 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
         const int o = 16 * b;
         double a[16], t[16], dinv[16];
 #pragma unroll
-        for (int j = 0; j < 16; ++j) a[j] = S[(o + col) * LDW + o + j];
+        for (int j = 0; j < 16; ++j) a[j] = PADL(b == NB - 1, o + col, o + j);
         DiagStep<0>::run(a, dinv, col, bad);
         InvStep<0>::run(a, dinv, t, col);
         wv_sync();
         if (i < 16) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) S[(o + j) * LDW + o + col] = t[j];     // column col of T_bb replaces the tile
+            for (int j = 0; j < 16; ++j) PADS(b == NB - 1, o + j, o + col, t[j]);     // column col of T_bb replaces the tile
         }
         wv_sync();
 #pragma unroll
@@ -446,10 +451,10 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
             d4 acc = {0, 0, 0, 0};
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                acc = mfma_f64(S[(16 * ib + col) * LDW + o + 4 * s + kq], S[(o + col) * LDW + o + 4 * s + kq], acc);
+                acc = mfma_f64(PADL(ib == NB - 1, 16 * ib + col, o + 4 * s + kq), S[(o + col) * LDW + o + 4 * s + kq], acc);
             wv_sync();
 #pragma unroll
-            for (int r4 = 0; r4 < 4; ++r4) S[(16 * ib + kq + 4 * r4) * LDW + o + col] = acc[r4];
+            for (int r4 = 0; r4 < 4; ++r4) PADS(ib == NB - 1, 16 * ib + kq + 4 * r4, o + col, acc[r4]);
         }
         wv_sync();
 #pragma unroll
@@ -458,12 +463,12 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
             for (int jb = b + 1; jb <= ib; ++jb) {
                 d4 acc;
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) acc[r4] = S[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col];
+                for (int r4 = 0; r4 < 4; ++r4) acc[r4] = PADL(ib == NB - 1, 16 * ib + kq + 4 * r4, 16 * jb + col);
 #pragma unroll
                 for (int s = 0; s < 4; ++s)
-                    acc = mfma_f64(-S[(16 * ib + col) * LDW + o + 4 * s + kq], S[(16 * jb + col) * LDW + o + 4 * s + kq], acc);
+                    acc = mfma_f64(-PADL(ib == NB - 1, 16 * ib + col, o + 4 * s + kq), PADL(jb == NB - 1, 16 * jb + col, o + 4 * s + kq), acc);
 #pragma unroll
-                for (int r4 = 0; r4 < 4; ++r4) S[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = acc[r4];
+                for (int r4 = 0; r4 < 4; ++r4) PADS(ib == NB - 1, 16 * ib + kq + 4 * r4, 16 * jb + col, acc[r4]);
             }
         wv_sync();
     }
@@ -483,12 +488,12 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
                 for (int s = 0; s < 4; ++s) {
                     const int kk = 4 * s + kq;
                     const double tv = jb == b ? S[(16 * b + kk) * LDW + 16 * b + col] : S[(16 * b + col) * LDW + 16 * jb + kk];
-                    w = mfma_f64(S[(16 * ib + col) * LDW + 16 * jb + kk], tv, w);
+                    w = mfma_f64(PADL(ib == NB - 1, 16 * ib + col, 16 * jb + kk), tv, w);
                 }
             d4 o4 = {0, 0, 0, 0};
 #pragma unroll
             for (int r = 0; r < 4; ++r)         // the D registers of w are the B operand of k-step r with k = kq + 4 r
-                o4 = mfma_f64(-S[(16 * ib + col) * LDW + 16 * ib + kq + 4 * r], w[r], o4);
+                o4 = mfma_f64(-PADL(ib == NB - 1, 16 * ib + col, 16 * ib + kq + 4 * r), w[r], o4);
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) S[(16 * b + col) * LDW + 16 * ib + kq + 4 * r4] = o4[r4];
             wv_sync();
@@ -510,8 +515,8 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) {
                         const int kk = 4 * s + kq;
-                        const double av = kb == ib ? S[(16 * ib + kk) * LDW + 16 * ib + col] : S[(16 * ib + col) * LDW + 16 * kb + kk];
-                        const double bv = kb == jb ? S[(16 * jb + kk) * LDW + 16 * jb + col] : S[(16 * jb + col) * LDW + 16 * kb + kk];
+                        const double av = kb == ib ? PADL(ib == NB - 1, 16 * ib + kk, 16 * ib + col) : S[(16 * ib + col) * LDW + 16 * kb + kk];
+                        const double bv = kb == jb ? PADL(jb == NB - 1, 16 * jb + kk, 16 * jb + col) : S[(16 * jb + col) * LDW + 16 * kb + kk];
                         acc = mfma_f64(av, bv, acc);
                     }
                 hacc[ib * (ib + 1) / 2 + jb] = acc;
@@ -524,8 +529,8 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
 #pragma unroll
                 for (int r4 = 0; r4 < 4; ++r4) {
                     const double v = hacc[ib * (ib + 1) / 2 + jb][r4];
-                    sHi[(16 * ib + kq + 4 * r4) * LDW + 16 * jb + col] = v;
-                    sHi[(16 * jb + col) * LDW + 16 * ib + kq + 4 * r4] = v;
+                    PADS(ib == NB - 1, 16 * ib + kq + 4 * r4, 16 * jb + col, v);
+                    PADS(jb == NB - 1, 16 * jb + col, 16 * ib + kq + 4 * r4, v);
                 }
     }
     wv_sync();
@@ -663,7 +668,7 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st, bool probe) {
     if (h->n <= 64) {       // one wave per model
         const int nb = ceil_div(h->n, 16);
         const size_t npd = 16 * (size_t)nb;
-        const size_t wl = (npd * (npd + 1) + h->n + std::max<size_t>((size_t)h->n * (h->dims.nx + 1), 2 * (size_t)h->n)) * sizeof(double);
+        const size_t wl = ((size_t)h->n * (npd + 1) + h->n + std::max<size_t>((size_t)h->n * (h->dims.nx + 1), 2 * (size_t)h->n)) * sizeof(double);
         auto kern = nb == 1 ? &factor_wave_kernel<1> : nb == 2 ? &factor_wave_kernel<2> : nb == 3 ? &factor_wave_kernel<3> : &factor_wave_kernel<4>;
         e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(kern), wl);
         if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }
