@@ -188,6 +188,16 @@ def cpu_baseline_box(prob, seconds, what):
                                              f"steps, {bad2} failed"}
         except Exception as e:      # noqa: BLE001
             out["same_algorithm"] = {"value": None, "what": f"failed: {e!r}"}
+    if hasattr(cb, "solve_batch_box_activeset_split"):
+        try:
+            ns2 = int(min(len(prob["x0"]), 8 * nsamp))
+            _, st4, bad4, t4, nc4 = cb.solve_batch_box_activeset_split(H, F, f0, lb, ub, prob["x0"][:ns2], nthreads=cores)
+            out["same_algorithm_split"] = {"value": ns2 / t4, "unit": "solves/s", "cores": cores, "components": int(nc4),
+                                           "what": "the same C routine block by block where the Hessian splits (the GPU's "
+                                                   f"component split, DESIGN.md 4b); first {ns2} x0, mean {float(st4.mean()):.1f} "
+                                                   f"steps summed over {nc4} blocks, {bad4} failed"}
+        except Exception as e:      # noqa: BLE001
+            out["same_algorithm_split"] = {"value": None, "what": f"failed: {e!r}"}
     return out
 
 

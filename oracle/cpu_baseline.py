@@ -72,6 +72,38 @@ def solve_batch_box_activeset(H, F, f0, lb, ub, x0, nthreads=1):
     return U, st, bad, time.perf_counter() - t
 
 
+def solve_batch_box_activeset_split(H, F, f0, lb, ub, x0, nthreads=1, tol=1e-14):
+    """The same with the GPU's component split (mpc_amd/csrc/split.hip): rows that the Jacobi-scaled Hessian and its inverse
+    do not couple (|entry| <= tol of the unit diagonal) form independent box QPs, solved block by block with the same C
+    routine.  Returns (U, steps, n_failed, seconds, n_components); one component = the unsplit call."""
+    from scipy.sparse.csgraph import connected_components
+    lib = load()
+    H, F, f0, lb, ub, x0 = [np.ascontiguousarray(a, dtype=np.float64) for a in (H, F, f0, lb, ub, x0)]
+    n, nx = F.shape
+    B = x0.shape[0]
+    d = 1.0 / np.sqrt(np.diag(H))
+    Hs = H * d[:, None] * d[None, :]
+    His = np.linalg.inv(0.5 * (Hs + Hs.T)); His = 0.5 * (His + His.T)
+    dg = np.sqrt(np.diag(His))
+    ncomp, lab = connected_components((np.abs(Hs) > tol) | (np.abs(His) > tol * dg[:, None] * dg[None, :]), directed=False)
+    Hi = His * d[:, None] * d[None, :]
+    parts = []
+    for c in range(ncomp):
+        idx = np.where(lab == c)[0]
+        parts.append((idx, np.ascontiguousarray(Hi[np.ix_(idx, idx)]), np.ascontiguousarray(F[idx]), np.ascontiguousarray(f0[idx]),
+                      np.ascontiguousarray(lb[idx]), np.ascontiguousarray(ub[idx]), np.zeros((B, idx.size)), np.zeros(B, dtype=np.int32)))
+    bad = 0
+    t = time.perf_counter()
+    for idx, Hc, Fc, fc, lc, uc, Uc, sc in parts:
+        bad += lib.qp_activeset_batch_box(idx.size, nx, B, _p(Hc), _p(Fc), _p(fc), _p(lc), _p(uc), _p(x0), _p(Uc),
+                                          sc.ctypes.data_as(C.POINTER(C.c_int)), int(nthreads))
+    t = time.perf_counter() - t
+    U = np.zeros((B, n)); st = np.zeros(B, dtype=np.int32)
+    for idx, _, _, _, _, _, Uc, sc in parts:
+        U[:, idx] = Uc; st += sc
+    return U, st, bad, t, ncomp
+
+
 def solve_dense(P, q, G, h, abstol=1e-7, reltol=1e-6, feastol=1e-7, maxiters=100):
     lib = load()
     P, q, G, h = [np.ascontiguousarray(a, dtype=np.float64) for a in (P, q.reshape(-1), G, h.reshape(-1))]

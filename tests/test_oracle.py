@@ -182,6 +182,10 @@ def test_c_activeset_baseline_matches_golden(golden_dir):
         assert bad == 0 and (st >= 0).all()
         assert (np.abs(U - g["U"]).max(1) / np.abs(g["U"]).max(1)).max() <= 1e-8
         assert ((U >= ub - 1e-13) | (U <= lb + 1e-13)).sum(1).tolist() == (g["lam"] != 0).sum(1).tolist()
+        # block by block where the Hessian splits (bench.py's same_algorithm_split line): the same point, the same steps
+        U2, st2, bad2, _, nc = cb.solve_batch_box_activeset_split(g["H"], g["F"], g["f0"], lb, ub, g["x0"], nthreads=2)
+        assert nc == (4 if cfg == 3 else 1) and bad2 == 0
+        assert np.abs(U2 - U).max() <= 1e-10 * np.abs(U).max() and np.array_equal(st2, st)
 
 
 def test_sweep_fixtures_are_certified_and_reproducible():
