@@ -591,6 +591,7 @@ class LtvWorkload:
                                   cfg["u_max"], device=dev)
         self.x = torch.as_tensor(cfg["x0"][lo:hi], device=dev).contiguous()
         self.ks = torch.arange(1, self.N + 1, device=dev, dtype=torch.float64)
+        self.ahead = (cfg["v_ref"] * self.dt * self.ks).reshape(1, self.N)      # reference positions ahead of the rollout, (1, N)
         self.x_ref = torch.zeros((self.B, self.N, 4), dtype=torch.float64, device=dev)
         self.x_ref[:, :, 3] = cfg["v_ref"]
         self.units_per_step = self.global_batch
@@ -599,7 +600,7 @@ class LtvWorkload:
 
     def step(self):
         cfg = self.cfg
-        self.x_ref[:, :, 0] = self.x[:, :1] + cfg["v_ref"] * self.dt * self.ks
+        self.torch.add(self.x[:, :1], self.ahead, out=self.x_ref[:, :, 0])             # one launch: x + v_ref dt k into the strided column
         u0 = self.loop.step(self.x, self.x_ref, warm=True)
         self.x = self.loop.model.step(self.x, u0)
         self.nsteps += 1

@@ -192,6 +192,8 @@ int mpcqp_predict(mpcqp_handle h, const double* x0, const double* U, int batch, 
  * SE3Planner.py:194-195): when the next QP is posed in increments about the shifted previous plan, the kept primal
  * state is zeroed (the plan itself is the new origin) while the kept multipliers still mark the active bounds */
 int mpcqp_recenter(mpcqp_handle h, void* stream);
+/* mpcqp_shift followed by mpcqp_recenter as one launch (what a re-linearising closed loop does every step) */
+int mpcqp_shift_recenter(mpcqp_handle h, void* stream);
 
 /* -- introspection (device -> caller's device buffers; for tests and parity reports) --- */
 /* which: 0 H (n,n)  1 F (n,nx)  2 f0 (n)  3 Gamma (N nx, n)  4 Phi (N nx, nx)

@@ -63,6 +63,7 @@ SYMBOLS = [
     ("mpcqp_shift", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_predict", C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     ("mpcqp_recenter", C.c_int, [C.c_void_p, C.c_void_p]),
+    ("mpcqp_shift_recenter", C.c_int, [C.c_void_p, C.c_void_p]),
     ("mpcqp_get", C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_long, C.c_void_p]),
     ("mpcqp_dense_workspace", C.c_long, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_long)]),
     ("mpcqp_remove_null_rows", C.c_int, [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_double] + [C.c_void_p] * 5),

@@ -66,7 +66,7 @@ int ensure_handover(mpcqp_handle h) {
 
 namespace {
 
-__global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int nu) {
+__global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int nu, int zero_z) {
     // one 64-lane wave per instance; rows move forward by one stage (nu rows), the last stage repeats
     const int inst = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (inst >= nblk) return;
@@ -76,7 +76,7 @@ __global__ void shift_kernel(double* z, double* w, int nblk, int NP, int n, int 
     for (int q = 0; q < 2; ++q) {
         const int r = lane + 64 * q;
         const int src = (r + nu < n) ? r + nu : r;
-        zv[q] = r < n ? zb[src] : 0.0;
+        zv[q] = (r < n && !zero_z) ? zb[src] : 0.0;
         wv[q] = r < n ? wb[src] : 0.0;
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
@@ -310,7 +310,17 @@ int mpcqp_shift(mpcqp_handle h, void* stream) {
     if (!h->has_state) { h->err = "shift: no solution state yet"; return MPCQP_ESTATE; }
     HIPCHK(h, hipSetDevice(h->dev));
     hipLaunchKernelGGL(shift_kernel, dim3(ceil_div(h->Blast, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       h->z, h->w, h->Blast, h->NP, h->n, h->dims.nu);
+                       h->z, h->w, h->Blast, h->NP, h->n, h->dims.nu, 0);
+    HIPCHK(h, hipGetLastError());
+    return MPCQP_OK;
+}
+
+int mpcqp_shift_recenter(mpcqp_handle h, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (!h->has_state) { h->err = "shift: no solution state yet"; return MPCQP_ESTATE; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    hipLaunchKernelGGL(shift_kernel, dim3(ceil_div(h->Blast, 4)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       h->z, h->w, h->Blast, h->NP, h->n, h->dims.nu, 1);
     HIPCHK(h, hipGetLastError());
     return MPCQP_OK;
 }

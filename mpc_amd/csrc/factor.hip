@@ -419,15 +419,37 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
             sF[i * nx1 + c] = v; Fs1[(size_t)i * nx1 + c] = v;
         }
     wv_sync();
-    for (int r = 0; r < n; ++r) {
-        if (in && i >= r) {
-            const double v = 0.5 * (S[r * LDW + i] + S[i * LDW + r]) * sd[r] * di;
-            S[r * LDW + i] = v;
-            S[i * LDW + r] = v;
+    // Hs = d (H + H')/2 d in two sweeps whose iterations do not depend on each other (eight rows' reads in flight; the
+    // row-by-row form with its mirrored store was a chain of n LDS round trips): the upper triangle from the raw entries --
+    // nothing below the diagonal is written in this sweep -- then the mirror image and the copy to global memory
+    for (int r0 = 0; r0 < n; r0 += 8) {
+        double av[8], bv[8], dv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            const bool on = in && r < n && i >= r;
+            av[u] = on ? S[r * LDW + i] : 0.0; bv[u] = on ? S[i * LDW + r] : 0.0; dv[u] = on ? sd[r] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            if (in && r < n && i >= r) S[r * LDW + i] = 0.5 * (av[u] + bv[u]) * dv[u] * di;
         }
     }
     wv_sync();
-    for (int r = 0; r < n; ++r) if (in) gHs[(size_t)r * n + i] = S[r * LDW + i];
+    for (int r0 = 0; r0 < n; r0 += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            v[u] = (in && r < n) ? (i >= r ? S[r * LDW + i] : S[i * LDW + r]) : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int r = r0 + u;
+            if (in && r < n) { if (i < r) S[r * LDW + i] = v[u]; gHs[(size_t)r * n + i] = v[u]; }
+        }
+    }
 #ifdef FAC_PROF
     { long long tk = wall_clock64(); t_ld += tk - tk0; tk0 = tk; }
 #endif
@@ -542,29 +564,33 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     double* __restrict__ Ku1 = f.Ku1 + m * n * nx1;
     double* __restrict__ FsT = f.FsT + m * NP * nx1;
     double* __restrict__ KuT = f.KuT + m * NP * nx1;
-    // Ku = -Hi [Fs | f0s], eight columns at a time: one read of Hi[i][k] serves them all
-    for (int c0 = 0; c0 < nx1; c0 += 8) {
-        double su[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (in) {
-#pragma unroll 2
-            for (int k = 0; k < n; ++k) {
-                const double hv = sHi[i * LDW + k];
+    // Ku = -Hi [Fs | f0s] as MFMA tiles, 16 columns of the map at a time: A = a row block of Hi, B' = [Fs | f0s]' (zero
+    // beyond its nx + 1 columns); the padding rows of the last block answer with the identity and are not stored
+    for (int c0 = 0; c0 < nx1; c0 += 16) {
+        const int c = c0 + col;
 #pragma unroll
-                for (int u = 0; u < 8; ++u) if (c0 + u < nx1) su[u] -= hv * sF[k * nx1 + c0 + u];
-            }
-        }
+        for (int ib = 0; ib < NB; ++ib) {
+            d4 acc = {0, 0, 0, 0};
 #pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            const int c = c0 + u;
-            if (c >= nx1) break;
-            if (in) Ku1[(size_t)i * nx1 + c] = su[u];
-            for (int r = i; r < NP; r += 64) {
-                FsT[c * NP + r] = r < n ? sF[r * nx1 + c] : 0.0;
-                if (r >= n) KuT[c * NP + r] = 0.0;
+            for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const int kk = 16 * kb + 4 * s + kq;
+                    const double bv = (c < nx1 && kk < n) ? sF[kk * nx1 + c] : 0.0;
+                    acc = mfma_f64(PADL(ib == NB - 1, 16 * ib + col, kk), bv, acc);
+                }
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int r = 16 * ib + kq + 4 * r4;
+                if (r < n && c < nx1) { Ku1[(size_t)r * nx1 + c] = -acc[r4]; KuT[c * NP + r] = -acc[r4]; }
             }
-            if (in) KuT[c * NP + i] = su[u];
         }
     }
+    for (int c = 0; c < nx1; ++c)
+        for (int r = i; r < NP; r += 64) {
+            FsT[c * NP + r] = r < n ? sF[r * nx1 + c] : 0.0;
+            if (r >= n) KuT[c * NP + r] = 0.0;
+        }
 #ifdef FAC_PROF
     { long long tk = wall_clock64(); t_ku += tk - tk0; tk0 = tk; }
 #endif
@@ -594,7 +620,7 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     const bool anybad = __any(bad);
     if (i == 0) {
         if (f.probe) atomicMax(reinterpret_cast<unsigned long long*>(f.rho_dev + 3), (unsigned long long)__double_as_longlong(e));
-        if (anybad) atomicOr(f.flag, 1);
+        if (anybad && f.probe) atomicOr(f.flag, 1);     // asynchronous calls report per model only (mflag): nobody reads the sum
         f.mflag[m] = anybad ? 1 : 0;
     }
     const double* umin = f.umin + m * f.bnd_stride;
@@ -661,7 +687,7 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st, bool probe) {
     f.use_lds = lds <= 128 * 1024;
     f.mflag = h->mflag;
     hipError_t e = probe ? hipMemsetAsync(h->rho_dev, 0, 4 * sizeof(double), st) : hipSuccess;      // only the probe writes it
-    if (e == hipSuccess) e = hipMemsetAsync(h->flag_dev, 0, sizeof(int), st);
+    if (e == hipSuccess && (probe || h->n > 64)) e = hipMemsetAsync(h->flag_dev, 0, sizeof(int), st);   // read back by synchronous calls only
     if (e == hipSuccess && f.use_lds)
         e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(&factor_batch_kernel), lds);
     if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }

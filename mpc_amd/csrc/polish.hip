@@ -537,6 +537,37 @@ __global__ __launch_bounds__(64 * WAVES) void polish_box_kernel(PolParams p) {
     polish_wave<KMAX>(p, inst, s, lane);
 }
 
+// Second pass on a short grid (a kernel of its own: one more way into polish_box_kernel cost its first-pass instantiation a
+// VGPR and with it a wave per SIMD): every wave looks through its share of the flags the first pass left, 64 per load, and takes
+// the instances it finds one after the other -- usually none, and then the launch is a few loads long instead of one wave per
+// instance that starts, reads one flag and ends
+template <int KMAX>
+__global__ __launch_bounds__(64) void polish_scan_kernel(PolParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    WaveLds<KMAX>& s = reinterpret_cast<WaveLds<KMAX>*>(smem)[0];
+    const int nw = (int)gridDim.x, per = ((p.B + nw - 1) / nw + 63) & ~63;
+    const int lo = blockIdx.x * per, hi = min(lo + per, p.B);
+    for (int base = lo; base < hi; base += 64) {
+        unsigned long long m = __ballot(base + lane < hi && p.need_big[base + lane] != 0);
+        while (m) {
+            const int j = __builtin_ctzll(m);
+            m &= m - 1;
+            polish_wave<KMAX>(p, base + j, s, lane);
+            wave_sync();
+        }
+    }
+}
+
+template <int KMAX>
+int launch_pol_scan(const PolParams& p, hipStream_t st) {
+    const size_t lds = sizeof(WaveLds<KMAX>);
+    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&polish_scan_kernel<KMAX>), lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL((polish_scan_kernel<KMAX>), dim3(std::min(ceil_div(p.B, 64), 1024)), dim3(64), lds, st, p);
+    return (int)hipGetLastError();
+}
+
 template <int KMAX, int WAVES>
 int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
     const size_t lds = sizeof(WaveLds<KMAX>) * WAVES;
@@ -694,7 +725,7 @@ int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const 
         }
     } else if (rc < 0) {
         rc = launch_pol<32, 4>(p, st);
-        if (rc == 0 && o.polish) { p.pass = 1; rc = launch_pol<128, 1>(p, st); }
+        if (rc == 0 && o.polish) { p.pass = 1; rc = launch_pol_scan<128>(p, st); }
     }
     if (rc != 0) { h->err = std::string("polish launch: ") + hipGetErrorString((hipError_t)rc); return MPCQP_EHIP; }
     return MPCQP_OK;

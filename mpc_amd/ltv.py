@@ -141,7 +141,7 @@ class ClosedLoopLTV:
         plan = ubar + dU
         self._gu0.copy_(plan[:, 0])
         ubar[:, :-1].copy_(plan[:, 1:]); ubar[:, -1].copy_(plan[:, -1])
-        pl.shift().recenter()
+        pl.shift(recenter=True)
 
     def step(self, x, x_ref, warm=True, **opts):
         """x (B,nx) current states, x_ref (B,N,nx) references for x_1..x_N.  Returns the applied input (B,nu)."""
@@ -180,7 +180,7 @@ class ClosedLoopLTV:
             plan = ubar + dU
             u0 = plan[:, 0].clone()
             self.plan = torch.cat((plan[:, 1:], plan[:, -1:]), dim=1).contiguous()
-        pl.shift().recenter()
+        pl.shift(recenter=True)
         # after the first (synchronous, validated) step the set-up calls no longer wait for the device
         pl.no_sync, pl.check_inputs = True, False
         return u0

@@ -429,9 +429,11 @@ class Planner:
         ci = _lib.Info(*[_ptr(getattr(info, f[0])) for f in _lib.Info._fields_])
         return U, info, ci
 
-    def shift(self):
-        """Receding horizon: move the kept primal/dual state one stage forward (last stage repeated)."""
-        self._check(self._lib.mpcqp_shift(self._h, self._stream()))
+    def shift(self, recenter=False):
+        """Receding horizon: move the kept primal/dual state one stage forward (last stage repeated); recenter=True also
+        zeroes the primal state in the same launch (shift().recenter() of a re-linearising loop)."""
+        fn = self._lib.mpcqp_shift_recenter if recenter else self._lib.mpcqp_shift
+        self._check(fn(self._h, self._stream()))
         return self
 
     def predict(self, x0, U):
