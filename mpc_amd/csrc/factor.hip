@@ -364,8 +364,11 @@ struct InvStep<16> {
 // The identity padding of the last row block (rows n .. 16 NB - 1) is not stored: every step leaves it what it was (L, T and
 // Hi of the padding are the identity, its off-diagonal tiles zero), so reads of those rows are answered with the constant
 // (PADL) and writes to them dropped -- 15.7 instead of 18.8 KB per wave at n = 40, nine waves per CU instead of seven.
+#ifndef FACW
+#define FACW 2
+#endif
 template <int NB>
-__global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
+__global__ __launch_bounds__(64, FACW) void factor_wave_kernel(FacBatchParams f) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int n = f.n, nx = f.nx, nx1 = f.nx + 1, NP = f.NP, i = threadIdx.x;
     constexpr int NPD = 16 * NB, LDW = NPD + 1;
@@ -382,43 +385,66 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
     // rows of the LAST row block may be padding (LASTB: a compile-time fact after unrolling; the test on r is then the only cost)
     auto PADL = [&](bool lastb, int r, int c) -> double { return (!lastb || r < n) ? S[r * LDW + c] : (r == c ? 1.0 : 0.0); };
     auto PADS = [&](bool lastb, int r, int c, double v) { if (!lastb || r < n) S[r * LDW + c] = v; };
-    double* sF = sd + n;                                  // (n, nx1) scaled [F | f0]; later two probe vectors
+    double* sP = sd + n;                                  // two probe vectors (synchronous calls only: the launch sizes the LDS)
     const bool in = i < n;
     bool bad = false;
     double di = 1.0;
 #ifdef FAC_PROF
     long long tk0 = wall_clock64(), t_ld = 0, t_chol = 0, t_inv = 0, t_hi = 0, t_ku = 0, t_pr = 0;
 #endif
-    // raw H into LDS (identity on the padding): the matrix as one flat array, 16 coalesced loads in flight per lane before the
-    // first LDS write waits for one (row by row the 40 loads of a bicycle model came back in 5 rounds of memory latency)
+    // Everything the wave needs from memory is asked for before anything waits: the diagonal entry of the lane's row (the
+    // Jacobi scale, without a trip through LDS), [F | f0] in the layout the Ku product at the end wants its B operand in
+    // (lane (c, kq) holds rows 16 kb + 4 s + kq of column c: registers, no LDS), and H as one flat array, 32 coalesced loads
+    // in flight per lane (row by row the 40 loads of a bicycle model came back in 5 rounds of memory latency).
+    const double hii = in ? H[(size_t)i * n + i] : 1.0;
+    double fb[NB][4];
+    auto loadF = [&](int c0) {
+        const int c = c0 + col;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kk = 16 * kb + 4 * s + kq;
+                fb[kb][s] = (kk < n && c < nx1) ? (c < nx ? F[(size_t)kk * nx + c] : f0[kk]) : 0.0;
+            }
+    };
+    loadF(0);
     {
         const int tot = n * n;
-        for (int base = 0; base < tot; base += 16 * 64) {
-            double hv[16];
+        for (int base = 0; base < tot; base += 32 * 64) {
+            double hv[32];
 #pragma unroll
-            for (int u = 0; u < 16; ++u) { const int idx = base + 64 * u + i; hv[u] = idx < tot ? H[idx] : 0.0; }
+            for (int u = 0; u < 32; ++u) { const int idx = base + 64 * u + i; hv[u] = idx < tot ? H[idx] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 16; ++u) {
+            for (int u = 0; u < 32; ++u) {
                 const int idx = base + 64 * u + i;
                 if (idx < tot) { const int r = idx / n; S[r * LDW + (idx - r * n)] = hv[u]; }
             }
         }
     }
     for (int idx = i; idx < n * (NPD - n); idx += 64) { const int r = idx / (NPD - n); S[r * LDW + n + (idx - r * (NPD - n))] = 0.0; }
-    wv_sync();
     if (in) {
-        const double hii = S[i * LDW + i];
         if (!(hii > 0.0)) bad = true; else di = 1.0 / sqrt(hii);
         sd[i] = di;
     }
-    // [Fs | f0s] = d [F | f0]: read now, so that the loads overlap the factorisation; needed again for Ku at the end
-    double* __restrict__ Fs1 = f.Fs1 + m * n * nx1;
-    if (in)
-        for (int c = 0; c < nx1; ++c) {
-            const double v = di * (c < nx ? F[(size_t)i * nx + c] : f0[i]);
-            sF[i * nx1 + c] = v; Fs1[(size_t)i * nx1 + c] = v;
-        }
     wv_sync();
+    double* __restrict__ Fs1 = f.Fs1 + m * n * nx1;
+    double* __restrict__ FsT = f.FsT + m * NP * nx1;
+    // [Fs | f0s] = d [F | f0], also transposed (nx+1, NP): straight from the registers (first 16 columns; the rest with Ku below)
+    auto scaleF = [&](int c0) {
+        const int c = c0 + col;
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const int kk = 16 * kb + 4 * s + kq;
+                if (kk < n && c < nx1) {
+                    fb[kb][s] *= sd[kk];
+                    Fs1[(size_t)kk * nx1 + c] = fb[kb][s]; FsT[c * NP + kk] = fb[kb][s];
+                }
+            }
+    };
+    scaleF(0);
     // Hs = d (H + H')/2 d in two sweeps whose iterations do not depend on each other (eight rows' reads in flight; the
     // row-by-row form with its mirrored store was a chain of n LDS round trips): the upper triangle from the raw entries --
     // nothing below the diagonal is written in this sweep -- then the mirror image and the copy to global memory
@@ -560,14 +586,14 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
 #ifdef FAC_PROF
     { long long tk = wall_clock64(); t_hi += tk - tk0; tk0 = tk; }
 #endif
-    // [Fs | f0s] and [Ku | ku], also transposed (nx+1, NP)
+    // [Ku | ku], also transposed (nx+1, NP)
     double* __restrict__ Ku1 = f.Ku1 + m * n * nx1;
-    double* __restrict__ FsT = f.FsT + m * NP * nx1;
     double* __restrict__ KuT = f.KuT + m * NP * nx1;
     // Ku = -Hi [Fs | f0s] as MFMA tiles, 16 columns of the map at a time: A = a row block of Hi, B' = [Fs | f0s]' (zero
     // beyond its nx + 1 columns); the padding rows of the last block answer with the identity and are not stored
     for (int c0 = 0; c0 < nx1; c0 += 16) {
         const int c = c0 + col;
+        if (c0 > 0) { loadF(c0); scaleF(c0); }
 #pragma unroll
         for (int ib = 0; ib < NB; ++ib) {
             d4 acc = {0, 0, 0, 0};
@@ -576,8 +602,7 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const int kk = 16 * kb + 4 * s + kq;
-                    const double bv = (c < nx1 && kk < n) ? sF[kk * nx1 + c] : 0.0;
-                    acc = mfma_f64(PADL(ib == NB - 1, 16 * ib + col, kk), bv, acc);
+                    acc = mfma_f64(PADL(ib == NB - 1, 16 * ib + col, kk), fb[kb][s], acc);
                 }
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
@@ -587,10 +612,7 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
         }
     }
     for (int c = 0; c < nx1; ++c)
-        for (int r = i; r < NP; r += 64) {
-            FsT[c * NP + r] = r < n ? sF[r * nx1 + c] : 0.0;
-            if (r >= n) KuT[c * NP + r] = 0.0;
-        }
+        for (int r = n + i; r < NP; r += 64) { FsT[c * NP + r] = 0.0; KuT[c * NP + r] = 0.0; }
 #ifdef FAC_PROF
     { long long tk = wall_clock64(); t_ku += tk - tk0; tk0 = tk; }
 #endif
@@ -605,8 +627,8 @@ __global__ __launch_bounds__(64) void factor_wave_kernel(FacBatchParams f) {
             for (int j = 0; j < n; ++j) { const double hv = sHi[i * LDW + j]; v1 += hv; v2 += (j & 1) ? -hv : hv; }
         }
         wv_sync();
-        double* p1 = sF;                      // [F | f0] is dead: reuse its space (sized for both uses)
-        double* p2 = sF + n;
+        double* p1 = sP;
+        double* p2 = sP + n;
         if (in) { p1[i] = v1; p2[i] = v2; }
         wv_sync();
         if (in) {
@@ -694,7 +716,7 @@ int launch_factor_batch(mpcqp_handle h, hipStream_t st, bool probe) {
     if (h->n <= 64) {       // one wave per model
         const int nb = ceil_div(h->n, 16);
         const size_t npd = 16 * (size_t)nb;
-        const size_t wl = ((size_t)h->n * (npd + 1) + h->n + std::max<size_t>((size_t)h->n * (h->dims.nx + 1), 2 * (size_t)h->n)) * sizeof(double);
+        const size_t wl = ((size_t)h->n * (npd + 1) + h->n + (probe ? 2 * (size_t)h->n : 0)) * sizeof(double);
         auto kern = nb == 1 ? &factor_wave_kernel<1> : nb == 2 ? &factor_wave_kernel<2> : nb == 3 ? &factor_wave_kernel<3> : &factor_wave_kernel<4>;
         e = ensure_dyn_lds(h->dev, reinterpret_cast<const void*>(kern), wl);
         if (e != hipSuccess) { h->err = std::string("factor (batch): ") + hipGetErrorString(e); return MPCQP_EHIP; }

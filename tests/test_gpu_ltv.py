@@ -128,6 +128,56 @@ def test_bicycle_closed_loop_matches_oracle_and_converges():
     assert np.mean(steps_used[-10:]) <= 1.0
 
 
+def test_full_size_closed_loop_keeps_lane_bounds_and_optimality():
+    """configs[3] at its stated size: 8,192 rollouts, 300 closed-loop steps (every rollout re-linearised, assembled, factored
+    and solved each step), checked through properties that need no oracle: every step of every rollout reports SOLVED and
+    applies an input inside the box (accumulated on the device, one read-back at the end); every rollout ends in its lane;
+    the shifted multipliers keep the late steps at (almost) no active-set change; and the LAST step's QP of 64 rollouts
+    spread over the batch meets the KKT conditions evaluated from that rollout's own H and f0 (mpcqp_get)."""
+    import torch
+    from mpc_amd.configs import make_config
+    from mpc_amd.ltv import Bicycle, ClosedLoopLTV
+    cfg = make_config(4, seed=3)
+    Bn = cfg["x0"].shape[0]
+    assert Bn == 8192
+    N, dt, L = cfg["N"], cfg["dt"], cfg["L"]
+    dev = torch.device("cuda:0")
+    loop = ClosedLoopLTV(Bicycle(L, dt), N, cfg["Q"], cfg["R"], cfg["P"], cfg["u_min"], cfg["u_max"], device=dev)
+    x = torch.as_tensor(cfg["x0"], device=dev)
+    y0 = x[:, 1].abs().clone()
+    ahead = (cfg["v_ref"] * dt * torch.arange(1, N + 1, device=dev, dtype=torch.float64)).reshape(1, N)
+    x_ref = torch.zeros((Bn, N, 4), dtype=torch.float64, device=dev)
+    x_ref[:, :, 3] = cfg["v_ref"]
+    umin = torch.as_tensor(cfg["u_min"], device=dev); umax = torch.as_tensor(cfg["u_max"], device=dev)
+    worst_status = torch.zeros((), dtype=torch.int32, device=dev)
+    worst_excess = torch.zeros((), dtype=torch.float64, device=dev)
+    late_steps = torch.zeros((), dtype=torch.float64, device=dev)
+    for it in range(300):
+        torch.add(x[:, :1], ahead, out=x_ref[:, :, 0])
+        u0 = loop.step(x, x_ref)
+        worst_status = torch.maximum(worst_status, loop.pl.info.status.max())
+        worst_excess = torch.maximum(worst_excess, torch.maximum(u0 - umax, umin - u0).max())
+        if it >= 290:
+            late_steps += loop.pl.info.polish_steps.double().mean()
+        x = loop.model.step(x, u0)
+    assert int(worst_status) == 0
+    assert float(worst_excess) <= 1e-9
+    assert float(late_steps) / 10 <= 1.0
+    assert bool((x[:, 1].abs() < 0.05 + 0.05 * y0).all()) and bool((x[:, 2].abs() < 0.05).all())
+    assert bool(((x[:, 3] - cfg["v_ref"]).abs() < 0.2).all())
+    # KKT of the last QP (increments about the plan; x0 = 0, so q = f0), from the rollout's own assembled matrices
+    dU = loop.last["dU"].reshape(Bn, -1)
+    lb = (umin - loop.last["ubar"]).reshape(Bn, -1); ub = (umax - loop.last["ubar"]).reshape(Bn, -1)
+    for i in range(0, Bn, 128):
+        H = loop.pl.get("H", model=i); q = loop.pl.get("f0", model=i)
+        u = dU[i]; g = H @ u + q
+        sc = max(float(q.abs().max()), 1.0)
+        assert bool((u <= ub[i] + 1e-9).all()) and bool((u >= lb[i] - 1e-9).all()), i
+        free = (u < ub[i] - 1e-9) & (u > lb[i] + 1e-9)
+        assert float((g.abs() * free).max()) <= 1e-8 * sc, i
+        assert bool(((g <= 1e-8 * sc) | (u < ub[i] - 1e-9)).all()) and bool(((g >= -1e-8 * sc) | (u > lb[i] + 1e-9)).all()), i
+
+
 def test_closed_loop_graph_replay_matches_eager_steps():
     """One closed-loop step recorded as a HIP graph (linearise -> assemble -> factor -> solve -> apply -> shift, no host
     work in between) drives the rollouts exactly like the eager step() does."""
