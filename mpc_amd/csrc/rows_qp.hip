@@ -117,6 +117,92 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams g) {
             }
 }
 
+// The same tile with the operands staged through LDS: a 64 x 32 chunk of A and of B per step, fetched by the whole workgroup
+// with row-contiguous 16-byte loads (16 lanes per row: every line once per workgroup -- the kernel above has each wave fetch
+// its own 32 rows, lane by lane 16 rows apart, so every operand line crosses the CU's L1 twice and its address unit sixteen
+// lines per instruction), held in registers while the previous chunk is multiplied, then written to LDS rows 34 doubles apart
+// (row r starts on bank 4 r mod 64: the 16 rows of an MFMA operand read, 16 bytes each, cover all 64 banks once).
+// Needs 16-byte aligned operands and an even K (launch_gemm_nt checks); the k order inside a 16-step is the same as above.
+__global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams g) {
+    constexpr int KC = 32, LD = KC + 2;
+    __shared__ __attribute__((aligned(16))) double sA[64 * LD];
+    __shared__ __attribute__((aligned(16))) double sB[64 * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int bi = blockIdx.y * 64, bj = blockIdx.x * 64;
+    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    d4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = d4{0, 0, 0, 0};
+    // staging: thread -> (row = tid / 16 + 16 u, doubles 2 (tid % 16), +1) of the chunk, u = 0..3
+    const int sr = tid >> 4, sc = 2 * (tid & 15);
+    const double* ga[4]; const double* gb[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        ga[u] = g.A + (size_t)min(bi + sr + 16 * u, g.M - 1) * g.lda + sc;      // rows beyond the matrix: a copy of the last row,
+        gb[u] = g.B + (size_t)min(bj + sr + 16 * u, g.N - 1) * g.ldb + sc;      // whose products are never stored
+    }
+    double2 ra[4], rb[4];
+    auto fetch = [&](int k0) {
+        const bool on = k0 + sc < g.K;          // K is even: a pair is inside or outside as a whole
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ra[u] = on ? *reinterpret_cast<const double2*>(ga[u] + k0) : double2{0.0, 0.0};
+            rb[u] = on ? *reinterpret_cast<const double2*>(gb[u] + k0) : double2{0.0, 0.0};
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += KC) {
+        __syncthreads();                        // the previous chunk has been read by every wave
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            *reinterpret_cast<double2*>(&sA[(sr + 16 * u) * LD + sc]) = ra[u];
+            *reinterpret_cast<double2*>(&sB[(sr + 16 * u) * LD + sc]) = rb[u];
+        }
+        __syncthreads();
+        if (k0 + KC < g.K) fetch(k0 + KC);      // in flight while this chunk is multiplied
+#pragma unroll
+        for (int ks = 0; ks < KC; ks += 16) {
+            double2 a[2][2], b[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                a[t][0] = *reinterpret_cast<const double2*>(&sA[(wi + 16 * t + col) * LD + ks + 4 * kq]);
+                a[t][1] = *reinterpret_cast<const double2*>(&sA[(wi + 16 * t + col) * LD + ks + 4 * kq + 2]);
+                b[t][0] = *reinterpret_cast<const double2*>(&sB[(wj + 16 * t + col) * LD + ks + 4 * kq]);
+                b[t][1] = *reinterpret_cast<const double2*>(&sB[(wj + 16 * t + col) * LD + ks + 4 * kq + 2]);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+                    for (int tj = 0; tj < 2; ++tj) {
+                        const double av = (e & 1) ? a[ti][e >> 1].y : a[ti][e >> 1].x;
+                        const double bv = (e & 1) ? b[tj][e >> 1].y : b[tj][e >> 1].x;
+                        acc[ti][tj] = mfma_f64(av, bv, acc[ti][tj]);
+                    }
+        }
+    }
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < 2; ++tj)
+#pragma unroll
+            for (int r4 = 0; r4 < 4; ++r4) {
+                const int i = bi + wi + 16 * ti + kq + 4 * r4, j = bj + wj + 16 * tj + col;
+                if (i < g.M && j < g.N) {
+                    double* c = g.C + (size_t)i * g.ldc + j;
+                    double v = g.alpha * acc[ti][tj][r4];
+                    if (g.bias) v += g.bias[j];
+                    if (g.cscale) v = g.cdiv ? v / g.cscale[j] : v * g.cscale[j];
+                    if (g.beta != 0.0) v += g.beta * (g.Cin ? g.Cin[(size_t)i * g.ldc + j] : *c);
+                    *c = v;
+                }
+            }
+}
+
 // The same product when C is small and K long (Xu = -Qs Hi: 256 x 600 over K = 600 is 40 of the tiles above, each walking
 // all of K): 32 x 32 per workgroup and the FOUR WAVES SPLIT K, each accumulating the whole tile over its quarter; the
 // partial tiles meet in LDS in a fixed order (deterministic), wave w finishes rows 8w .. 8w+7.  Four times the workgroups and
@@ -207,6 +293,8 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
     g.vec = (lda % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0);
     if ((long)ceil_div(N, 64) * ceil_div(M, 64) < 128 && K >= 256)      // few tiles, long K: split K over the waves
         hipLaunchKernelGGL(gemm_nt_splitk_kernel, dim3(ceil_div(N, 32), ceil_div(M, 32)), dim3(256), 0, st, g);
+    else if (g.vec && K % 2 == 0 && K >= 64 && M >= 64 && N >= 64)
+        hipLaunchKernelGGL(gemm_nt_lds_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
     else
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
