@@ -1124,6 +1124,8 @@ int launch_oct_split(const PolParams& p, int slots, hipStream_t st) {
         if (n <= 16) return launch_oct_c<8, 1, 16, 512, true, true>(p, p.B, st);
         if (n <= 32) return launch_oct_c<8, 2, 16, 512, true, true>(p, p.B, st);
         if (n <= 64) return launch_oct_c<8, 4, 16, 512, true, true>(p, p.B, st);
+    } else if (slots == 17) {           // 16 slots, 16 lanes per sub-instance: the first pass of the smallest batches (split.hip)
+        if (n <= 32) return launch_oct_c<16, 1, 16, 512, true, true>(p, p.B, st);
     } else if (slots == 32) {
         if (n <= 32) return launch_oct_c<16, 1, 32, 512, true, true>(p, p.B, st);
         if (n <= 64) return launch_oct_c<16, 2, 32, 512, true, true>(p, p.B, st);

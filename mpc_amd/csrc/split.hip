@@ -241,7 +241,10 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     a.qin = nullptr; a.qin_count = nullptr; a.hand_in = nullptr;
     if (small) { a.qout = w.q2; a.qout_count = w.counters + 1; a.hand_out = h->sp_hb2; a.hand_out_cap = h->sp_cap2; }
     else { a.qout = w.q1; a.qout_count = w.counters; a.hand_out = h->sp_hb1; a.hand_out_cap = h->sp_cap1; }
-    rc = launch_oct_split(a, small ? 16 : 8, st);
+    // up to 4,096 x 4 sub-instances the 16-slot pass runs with 16 lanes per sub-instance (two rows per lane: a shorter step, four
+    // per wave): 4,096 instances 70 -> 63 us, 1,024: 62 -> 57; equal at 8,192 x 4, slower beyond (12,288: 79 -> 93 us)
+    const bool wide = small && (long)Binst * C <= 20000 && h->sp_ld == 32;
+    rc = launch_oct_split(a, small ? (wide ? 17 : 16) : 8, st);
     if (rc != 0) return leave(rc);
     if (stop_after == 1) return leave(0);      // timing of the first pass alone (bench.py): the batch is left partly solved
     if (!small) {

@@ -584,4 +584,5 @@ def test_a_recorded_solve_replays_bit_for_bit(cfg, batch, split):
     with pytest.raises(RuntimeError, match="closed"):
         g.replay()
     pl.set_cost(prob["Q"], prob["R"], prob["P"]).setup()
-    assert torch.equal(pl.solve(big)[:batch], Ua)
+    # (another batch size may take other kernels: the same point to rounding, not to the bit)
+    assert float((pl.solve(big)[:batch] - Ua).abs().max()) <= 1e-11 * float(Ua.abs().max())
