@@ -291,6 +291,15 @@ int  mpcqp_rows_solve(int device_id, int batch, int n, int m, const double* q, c
 int  mpcqp_rows_solve_mpc(int device_id, int batch, int n, int m, int nx, const double* x0, const double* F,
                           const double* f0, const double* E, const double* h0, double* x, double* z, double* obj,
                           int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream);
+/* the same, started from the working set each instance's PREVIOUS solve in this instance_ws ended with (every solve leaves
+ * it there): for loops that solve the same model again from nearby data -- the reference's sequential QPs,
+ * CollocationBasedPlanner2D.py:85-365, SE3Planner.py:108-195.  Members of the kept set whose multiplier comes out with the
+ * wrong sign for the new data are released first; the minimiser found is the same as a cold solve's.  Only valid when the
+ * last call on this instance_ws was a solve of the same batch on the same shared_ws (mpcqp_solve with warm_start = 1 in
+ * the general-constraint mode checks that and falls back to a cold solve otherwise). */
+int  mpcqp_rows_solve_mpc_warm(int device_id, int batch, int n, int m, int nx, const double* x0, const double* F,
+                               const double* f0, const double* E, const double* h0, double* x, double* z, double* obj,
+                               int* status, int* iters, const double* shared_ws, double* instance_ws, void* stream);
 
 /* -- pre-solve row hygiene: removeNullConstraints(J, c, threshold) of HelperFuncs.py:41-54 (called at
  * CollocationBasedPlanner2D.py:338 on the stacked equality rows before they reach solvers.qp) -----------------------

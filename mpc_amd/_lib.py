@@ -81,6 +81,7 @@ SYMBOLS = [
     ("mpcqp_rows_workspace", C.c_long, [C.c_int, C.c_int, C.POINTER(C.c_long)]),
     ("mpcqp_rows_setup", C.c_int, [C.c_int] * 3 + [C.c_void_p] * 5),
     ("mpcqp_rows_solve", C.c_int, [C.c_int] * 4 + [C.c_void_p] * 10),
+    ("mpcqp_rows_solve_mpc_warm", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 13),
     ("mpcqp_rows_solve_mpc", C.c_int, [C.c_int] * 5 + [C.c_void_p] * 13),
 ]
 

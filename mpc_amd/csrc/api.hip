@@ -253,8 +253,10 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
     HIPCHK(h, hipSetDevice(h->dev));
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (h->general) {
-        if (o.warm_start) { h->err = "solve: the general-constraint path keeps no warm-start state"; return MPCQP_EINVAL; }
-        return solve_general(h, x0, batch, U, info, st);
+        // warm start: the constraint-space kernel continues from the working sets of the previous solve of the same batch (a cold
+        // solve if there is none); the dense kernel keeps no state
+        if (o.warm_start && !h->g_rows) { h->err = "solve: warm start in the general-constraint mode needs the constraint-space kernel (the dense kernel keeps no state)"; return MPCQP_EINVAL; }
+        return solve_general(h, x0, batch, U, info, st, o.warm_start);
     }
     TRY(ensure_batch(h, batch));
     if (o.warm_start && h->has_state && batch != h->Blast) { h->err = "solve: warm start needs the same batch as the previous solve"; return MPCQP_EINVAL; }

@@ -63,6 +63,7 @@ struct mpcqp_handle_s {
     long g_mem_limit = 32L << 30;           // bytes of shared workspace (the m x m dual Hessian) the constraint-space kernel may take
     bool general = false, g_rows = false;   // the last factorisation took the general path / the constraint-space kernel
     int g_m = 0, g_bcap = 0, g_dcap = 0; long g_per = 0;
+    int g_wvalid = 0;                            // batch whose final working sets the rows kernel's instance workspace holds (0: none)
     double *gG = nullptr, *gE = nullptr, *gh0 = nullptr;        // (m, n), (m, nx), (m): rows G U <= h0 - E x0, infinite bounds dropped
     double *g_shared = nullptr, *g_inst = nullptr, *g_q = nullptr, *g_hh = nullptr, *g_z = nullptr, *g_obj = nullptr, *g_dws = nullptr;
     int *g_iws = nullptr, *g_st = nullptr, *g_it = nullptr, *g_diws = nullptr;
@@ -115,5 +116,5 @@ int factor_general(mpcqp_handle h, hipStream_t st);
 // split.hip: look for independent components in the factored shared model (synchronises `st`); free its buffers
 int split_setup(mpcqp_handle h, hipStream_t st);
 void split_free(mpcqp_handle h);
-int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st);
+int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st, int warm);
 void general_free(mpcqp_handle h);

@@ -199,7 +199,7 @@ void general_free(mpcqp_handle h) {
     for (void* p : ptrs) if (p) (void)hipFree(p);
     h->gG = h->gE = h->gh0 = h->g_shared = h->g_inst = h->g_q = h->g_hh = h->g_z = h->g_obj = h->g_dws = nullptr;
     h->g_iws = h->g_st = h->g_it = h->g_diws = nullptr;
-    h->g_m = 0; h->g_bcap = 0; h->g_dcap = 0; h->general = false;
+    h->g_m = 0; h->g_bcap = 0; h->g_dcap = 0; h->general = false; h->g_wvalid = 0;
 }
 
 // synchronous (it is a set-up call): the number of rows that survive the pruning decides every later allocation
@@ -261,13 +261,14 @@ int factor_general(mpcqp_handle h, hipStream_t st) {
         rc = mpcqp_rows_setup(h->dev, n, m, h->H, h->gG, h->g_shared, h->g_iws, st);
         if (rc != MPCQP_OK) { h->err = "factor: mpcqp_rows_setup failed"; return rc; }
     }
-    h->general = true; h->factored = true; h->has_state = false; h->rho = 0.0;
+    h->general = true; h->factored = true; h->has_state = false; h->rho = 0.0; h->g_wvalid = 0;
     return MPCQP_OK;
 }
 
-int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st) {
+int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st, int warm) {
     const int n = h->n, m = h->g_m, nx = h->dims.nx;
-    if (B > h->g_bcap) {        // per-batch buffers (grow only; like ensure_batch this may allocate on the first larger batch)
+    if (B > h->g_bcap) {
+        h->g_wvalid = 0;        // per-batch buffers (grow only; like ensure_batch this may allocate on the first larger batch)
         if (h->pinned) { h->err = "solve: a larger batch would re-allocate workspaces that a recorded graph points into (mpcqp_pin)"; return MPCQP_ESTATE; }
         TRYG(grow(h, &h->g_z, (size_t)B * m));
         TRYG(grow(h, &h->g_obj, (size_t)B));
@@ -298,9 +299,12 @@ int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcq
                                     nullptr, 0, U, z, nullptr, obj, h->g_st, h->g_it, h->g_dws, h->g_diws, nullptr, st);
         if (rc != MPCQP_OK) { h->err = "solve: dense path (one model per instance) failed"; return rc; }
     } else if (h->g_rows) {
-        rc = mpcqp_rows_solve_mpc(h->dev, B, n, m, nx, x0, h->F, h->f0, h->gE, h->gh0, U, z, obj, h->g_st, h->g_it, h->g_shared,
-                                  h->g_inst, st);
+        // warm: from the working sets the previous solve of the same batch left in the instance workspace (rows_qp.hip)
+        const bool w = warm && h->g_wvalid == B;
+        rc = (w ? mpcqp_rows_solve_mpc_warm : mpcqp_rows_solve_mpc)(h->dev, B, n, m, nx, x0, h->F, h->f0, h->gE, h->gh0, U, z, obj, h->g_st,
+                                                                     h->g_it, h->g_shared, h->g_inst, st);
         if (rc != MPCQP_OK) { h->err = "solve: mpcqp_rows_solve_mpc failed"; return rc; }
+        h->g_wvalid = B;
     } else {
         long ni = 0;
         const long nd = mpcqp_dense_workspace(n, m, 0, &ni);

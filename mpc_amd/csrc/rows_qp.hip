@@ -305,7 +305,7 @@ struct Layout {
     // shared block: [dense set-up of "QP 0" | CH | Gram]
     long nd0;
     // per-instance block
-    long o_res, o_cs, o_qs, o_xu, o_x, o_t1, o_dv, o_slam, o_sact, stride;      // slam/sact: active set handed to pass 2
+    long o_res, o_cs, o_qs, o_xu, o_x, o_t1, o_dv, o_slam, o_sact, o_wact, stride;      // slam/sact: active set handed to pass 2; wact: the final set, kept for a warm start
 };
 
 // capacity of the active set: first pass (several workgroups per CU), second pass (one per CU, the LDS nearly full)
@@ -320,7 +320,8 @@ Layout make_layout(int n, int m) {
     l.o_res = 0; l.o_cs = me; l.o_qs = 2 * me; l.o_xu = l.o_qs + ne; l.o_x = l.o_xu + ne; l.o_t1 = l.o_x + ne; l.o_dv = l.o_t1 + ne;
     const long K2 = rows_kl2(n, m) + 3;
     l.o_slam = l.o_dv + ne; l.o_sact = l.o_slam + K2 + (K2 & 1);
-    l.stride = l.o_sact + (K2 + 1) / 2 + 1;
+    l.o_wact = l.o_sact + (K2 + 1) / 2 + 1;
+    l.stride = l.o_wact + (K2 + 1) / 2 + 1;
     l.stride += l.stride & 1;
     return l;
 }
@@ -363,7 +364,7 @@ struct RowsParams {
     Layout l;
     double *x, *z, *obj;
     int *status, *iters;
-    int n, m, B, KL, max_steps, refine, pass;
+    int n, m, B, KL, max_steps, refine, pass, warm;
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -471,7 +472,7 @@ __device__ void w0_remove(int* act, double* lam, int j, int k, int lane) {
 
 // L <- chol(Gram[act, act]); a member whose pivot falls below 1e-12 of its diagonal is dependent on the ones before
 // it and is removed.  Returns the (possibly reduced) k.
-__device__ int rows_rebuild(const double* Gram, int m, double* L, int* act, double* lam, int k, int* sflag) {
+__device__ int rows_rebuild(const double* Gram, int m, double* L, int* act, double* lam, int k, int* sflag, double thr = 1e-12) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (;;) {
         __syncthreads();
@@ -485,7 +486,7 @@ __device__ int rows_rebuild(const double* Gram, int m, double* L, int* act, doub
             for (int j = 0; j < k; ++j) {
                 const double dj = L[LIX(j, j)];
                 const double d0 = Gram[(size_t)act[j] * m + act[j]];
-                if (!(dj > 1e-12 * d0)) { bad = j; break; }
+                if (!(dj > thr * d0)) { bad = j; break; }
                 const double sj = sqrt(dj), inv = 1.0 / sj;
                 wave_sync();
                 if (lane == 0) L[LIX(j, j)] = sj;
@@ -540,7 +541,59 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     // hand-over between the passes: sact[0] = members saved by pass 1 (-1: none), sact[1] = its step count, sact[2..] = rows
     double* slam = c + p.l.o_slam;
     int* sact = reinterpret_cast<int*>(c + p.l.o_sact);
+    // the set the previous solve of this instance ended with (wact[0] members, -1: none): the start of a warm solve
+    int* wact = reinterpret_cast<int*>(c + p.l.o_wact);
     bool handed_over = false;
+    if (p.pass == 1 && p.warm && status == 0 && wact[0] > 0) {
+        // Warm start: take the kept set as the working set.  lam = S^-1 (N xu - cs)_A is the multiplier of "these rows hold with
+        // equality"; members it gives a wrong sign would be pulled the wrong way and leave (all at once, then again): what is left
+        // is the minimiser over a set of equalities with lam >= 0, a state the iteration below can continue from exactly as
+        // from one it built itself.  The residuals of all rows follow in one sweep, like one step's update.
+        k = min(wact[0], KL);
+        for (int a = tid; a < k; a += RT) { act[a] = wact[1 + a]; lam[a] = 0.0; }
+        for (;;) {
+            // a kept set may sit on a degenerate vertex (the iteration accepts pivots down to 1e-13): as a START only members
+            // that are clearly independent are taken (pivot > 1e-8 of the row's diagonal) -- the iteration adds what is missing
+            k = rows_rebuild(p.Gram, m, L, act, lam, k, &sflag, 1e-8);
+            if (k == 0) break;
+            for (int a = tid; a < k; a += RT) lam[a] = res[act[a]];
+            __syncthreads();
+            if (wave == 0) {
+                w0_fwd(L, k, lam, lane); w0_bwd(L, k, lam, lane);
+            }
+            __syncthreads();
+            // the multipliers must reproduce the right-hand side (S lam = rhs to 1e-9): if they do not, start cold
+            double bad = 0.0, big = 0.0;
+            for (int a = tid; a < k; a += RT) {
+                double v = 0.0;
+                for (int b = 0; b < k; ++b) v += p.Gram[(size_t)act[a] * m + act[b]] * lam[b];
+                bad = fabs(v - res[act[a]]); big = fabs(res[act[a]]);
+            }
+            double o; int oi;
+            blk_argmax(bad, 0, red, redi, o, oi); bad = o;
+            blk_argmax(big, 0, red, redi, o, oi); big = o;
+            __syncthreads();
+            if (!(bad <= 1e-9 * fmax(big, 1e-300))) { k = 0; break; }
+            if (wave == 0 && lane == 0) {
+                int kk = 0;
+                for (int a = 0; a < k; ++a) if (lam[a] > 0.0) { act[kk] = act[a]; ++kk; }
+                sflag = kk;
+            }
+            __syncthreads();
+            const int kk = sflag;
+            __syncthreads();
+            if (kk == k) break;
+            k = kk;
+            if (k == 0) break;
+        }
+        if (k > 0)
+            for (int r = tid; r < m; r += RT) {
+                double v = res[r];
+                for (int a = 0; a < k; ++a) v -= lam[a] * p.Gram[(size_t)act[a] * m + r];
+                res[r] = v;
+            }
+        __syncthreads();
+    }
     if (p.pass == 2) {
         if (status != 0 || p.status[qi] != 3 || sact[0] < 0) return;       // uniform over the workgroup
         k = sact[0]; steps = sact[1];
@@ -692,6 +745,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     const double eps = s.W0[2], tol = 1e-11;
     int rounds = 0;
     bool have_t1 = false;
+    double rm_last = 0.0, cm_last = 0.0, qm_last = 0.0;
     for (;;) {
         double wm = 0.0, qm = 0.0;
         for (int j = tid; j < n; j += RT) {                 // w = qs + N' lam
@@ -716,6 +770,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         blk_argmax(rm, 0, red, redi, o, oi); rm = o;
         blk_argmax(cm, 0, red, redi, o, oi); cm = o;
         __syncthreads();
+        rm_last = rm; cm_last = cm; qm_last = qm;
         TICK(t_nl)
         if (status != 0 || p.refine == 0) break;
         const bool rows_ok = rm <= tol * fmax(1.0, cm);
@@ -753,6 +808,19 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         TICK(t_rows)
     }
 
+    // What is about to be called SOLVED must hold its own active rows: a set that came to include a (numerically) dependent
+    // row -- an infeasible instance whose last row passed the dependency test by a hair -- carries multipliers of 1e15, and
+    // x = xu - CH' lam is then rounding noise that no refinement round repairs.  Such an instance is reported infeasible when
+    // its multipliers have run away, as a numerical failure otherwise; never as solved.
+    if (status == 0 && k > 0 && !(rm_last <= 1e-7 * fmax(1.0, cm_last))) {
+        double lm = 0.0;
+        for (int a = tid; a < k; a += RT) lm = fmax(lm, fabs(lam[a]));
+        double o; int oi;
+        blk_argmax(lm, 0, red, redi, o, oi);
+        __syncthreads();
+        status = o > 1e9 * fmax(1.0, fmax(qm_last, cm_last)) ? 2 : 3;
+    }
+
     // ---- outputs ----------------------------------------------------------------------------------------------------------
     double* xo = p.x + (size_t)qi * n;
     for (int j = tid; j < n; j += RT) xo[j] = status == 3 ? 0.0 : x[j] * s.d[j];
@@ -776,6 +844,10 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         printf("qp %d steps %d k %d: argmax %lld dir %lld update %lld book %lld final %lld = x %lld symv %lld nl %lld rows %lld out %lld (x10 ns)\n",
                qi, steps, k, t_arg, t_dir, t_upd, t_book, wall_clock64() - t_fin0, t_x, t_sv, t_nl, t_rows, t_out);
 #endif
+    if (!handed_over) {         // the final working set, for a warm start of the next solve (a handed-over instance: pass 2 writes it)
+        for (int a = tid; a < k; a += RT) wact[1 + a] = act[a];
+        if (tid == 0) wact[0] = status == 0 ? k : -1;
+    }
     if (tid == 0) {
         if (!handed_over) sact[0] = -1;
         if (p.obj) p.obj[qi] = obj;
@@ -848,7 +920,7 @@ struct MpcMaps { const double *x0, *F, *f0, *E, *h0; int nx; };
 
 static int rows_solve_impl(int device_id, int batch, int n, int m, const double* q, const double* h, const MpcMaps* mp,
                            double* x, double* z, double* obj, int* status, int* iters, const double* shared_ws,
-                           double* instance_ws, void* stream) {
+                           double* instance_ws, void* stream, int warm = 0) {
     if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const Layout l = make_layout(n, m);
@@ -882,6 +954,7 @@ static int rows_solve_impl(int device_id, int batch, int n, int m, const double*
     r.ws0 = shared_ws; r.CH = CH; r.Gram = Gram; r.inst = instance_ws; r.l = l;
     r.x = x; r.z = z; r.obj = obj; r.status = status; r.iters = iters;
     r.n = n; r.m = m; r.B = batch; r.max_steps = 20 * (n + m) + 100;
+    r.warm = warm ? 1 : 0;
     r.refine = 1;       // Hi is the exact-arithmetic inverse here (no proximal term): one round squares its rounding error
     auto lds_of = [&](int KL) {
         const size_t tri = (size_t)KL * (KL + 1) / 2;
@@ -915,6 +988,15 @@ int mpcqp_rows_solve_mpc(int device_id, int batch, int n, int m, int nx, const d
         return MPCQP_EINVAL;
     const MpcMaps mp{x0, F, f0, E, h0, nx};
     return rows_solve_impl(device_id, batch, n, m, nullptr, nullptr, &mp, x, z, obj, status, iters, shared_ws, instance_ws, stream);
+}
+
+int mpcqp_rows_solve_mpc_warm(int device_id, int batch, int n, int m, int nx, const double* x0, const double* F, const double* f0,
+                              const double* E, const double* h0, double* x, double* z, double* obj, int* status, int* iters,
+                              const double* shared_ws, double* instance_ws, void* stream) {
+    if (batch < 1 || n < 1 || m < 1 || nx < 1 || !x0 || !F || !f0 || !E || !h0 || !x || !status || !shared_ws || !instance_ws)
+        return MPCQP_EINVAL;
+    const MpcMaps mp{x0, F, f0, E, h0, nx};
+    return rows_solve_impl(device_id, batch, n, m, nullptr, nullptr, &mp, x, z, obj, status, iters, shared_ws, instance_ws, stream, 1);
 }
 
 }  // extern "C"

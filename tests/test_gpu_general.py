@@ -316,3 +316,78 @@ def test_rows_kernel_tail_refines_when_the_inverse_is_not_accurate_enough(cond):
         assert np.abs(g).max() <= 1e-8 * max(1.0, np.abs(q[i]).max()), i
         nact += int((zs[i] > 0).sum())
     assert nact >= B
+
+
+def test_warm_start_of_the_constraint_space_kernel_lands_on_the_cold_solution():
+    """warm_start in the general-constraint mode (mpcqp_rows_solve_mpc_warm): the solve starts from the working set the previous
+    solve of the same batch ended with.  (a) the same data again: confirmed without a step; (b) nearby data: the same minimiser
+    and multipliers as a cold solve of that data, in fewer steps; (c) data on the other side (x0 mirrored: every kept row
+    has the wrong sign): the wrong-signed members are released and the answer is still the cold one; (d) each against the
+    oracle; (e) another batch size, or a new factorisation, falls back to a cold solve; the dense kernel refuses."""
+    import torch
+    from mpc_amd.configs import long_horizon
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_qp
+    N, nx, nu, batch = 20, 10, 3, 24
+    prob = long_horizon(batch=batch, seed=11, N=N, nx=nx, nu=nu)
+    prob["x0"] *= 1.5
+
+    def planner(path="rows"):
+        pl = Planner(nx, nu, N).set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+        pl.general_path = path
+        return pl.set_constraints(prob["u_min"], prob["u_max"], x_min=prob["x_min"], x_max=prob["x_max"],
+                                  C=prob["C"], c_min=prob["c_min"], c_max=prob["c_max"])
+
+    rng = np.random.default_rng(5)
+    xa = prob["x0"]
+    xb = xa + 0.03 * rng.standard_normal(xa.shape) * np.abs(xa).max()
+    xc = -xa
+    cold = planner()
+    ref = {}
+    for name, x in (("a", xa), ("b", xb), ("c", xc)):
+        U = cold.solve(x, want_multipliers=True).cpu().numpy().reshape(batch, -1)
+        ref[name] = (U, cold.info.lam.cpu().numpy(), cold.info.status.cpu().numpy(), cold.info.obj.cpu().numpy(), cold.info.polish_steps.cpu().numpy())
+    assert (ref["a"][4] > 0).sum() >= batch // 2                   # rows do bind
+    # solved means feasible: an LP (largest common slack of all rows) says which instances have a feasible point at all --
+    # one of these is infeasible by 0.03 and used to come back SOLVED with multipliers of 1e15 (the last row passed the
+    # dependency test by a hair); now the kernel checks that what it calls solved holds its own active rows
+    from scipy.optimize import linprog
+    H, F, f0 = mo.condense(prob)
+    G, E, h0 = _oracle_rows(prob)
+    nvar = G.shape[1]
+    cost = np.zeros(nvar + 1); cost[-1] = -1.0
+    Aub = np.hstack([G, np.ones((G.shape[0], 1))])
+    for name, x in (("a", xa), ("b", xb), ("c", xc)):
+        for i in range(batch):
+            r = linprog(cost, A_ub=Aub, b_ub=h0 - E @ x[i], bounds=[(None, None)] * nvar + [(None, 10.0)], method="highs")
+            if r.x[-1] < -1e-6:
+                assert ref[name][2][i] != 0, (name, i, r.x[-1])
+            elif r.x[-1] > 1e-6:
+                assert ref[name][2][i] == 0, (name, i, r.x[-1])
+    assert (ref["a"][2] != 0).sum() >= 3
+    pl = planner()
+    pl.solve(xa)
+    seen = {}
+    for name, x in (("a", xa), ("b", xb), ("c", xc), ("b", xb)):
+        U = pl.solve(x, warm_start=True, want_multipliers=True).cpu().numpy().reshape(batch, -1)
+        Ur, lr, sr, objr, itr = ref[name]
+        st = pl.info.status.cpu().numpy(); it = pl.info.polish_steps.cpu().numpy()
+        assert np.array_equal(st, sr), name
+        ok = sr == 0
+        assert _rel(U[ok], Ur[ok]) <= 1e-9 and _rel(pl.info.lam.cpu().numpy()[ok], lr[ok]) <= 1e-8, name
+        assert _rel(pl.info.obj.cpu().numpy()[ok], objr[ok]) <= 1e-10, name
+        seen.setdefault(name, []).append((it[ok].sum(), itr[ok].sum()))
+    assert seen["a"][0][0] == 0                                     # the same data: nothing to do
+    assert seen["b"][0][0] < 0.5 * seen["b"][0][1]                  # nearby data: a fraction of the cold steps
+    # against the oracle (the cold answers are, elsewhere; here the warm ones of the last solve)
+    for i in range(0, batch, 5):
+        s = solve_qp(H, F @ xb[i] + f0, G, h0 - E @ xb[i])
+        if s["status"] == "optimal":
+            assert _rel(U[i], np.asarray(s["x"]).reshape(-1)) <= 1e-6, i
+    # another batch size: no kept sets for it -> a cold solve, same answer
+    U8 = pl.solve(xb[:8], warm_start=True).cpu().numpy().reshape(8, -1)
+    assert np.array_equal(pl.info.polish_steps.cpu().numpy(), ref["b"][4][:8])
+    assert _rel(U8[ref["b"][2][:8] == 0], ref["b"][0][:8][ref["b"][2][:8] == 0]) <= 1e-9
+    with pytest.raises(ValueError, match="dense kernel keeps no state"):
+        planner("dense").solve(xa, warm_start=True)
