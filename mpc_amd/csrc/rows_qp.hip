@@ -664,6 +664,64 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                 // after a full step with room for p the active set is act + {p}: the candidates of the next scan
                 const bool scan = full && k < KL;
                 fbest = 0.0; fbi = -1;
+                if ((m & 1) == 0) {
+                    // The sweep is a stream of (k + 2) rows of 8 m bytes through ONE CU, and what bounds it is how many bytes that CU
+                    // has in flight: with 8-byte loads and one active row at a time, 64 KB -- 25-40 GB/s at the latency of a
+                    // miss, 30 us per step at full size.  Here: 16-byte loads (row pairs; rows of an even m are 16-byte aligned)
+                    // and FOUR active rows' loads issued before the first is used: 256 KB in flight.  Same sums in the same order.
+                    const int m2 = m >> 1;
+                    const double2* Grow2 = reinterpret_cast<const double2*>(Grow);
+                    double2* res2 = reinterpret_cast<double2*>(res);
+                    const double2* cs2 = reinterpret_cast<const double2*>(cs);
+                    for (int q0 = 0; q0 < m2; q0 += 4 * RT) {
+                        double2 sv[4]; int q[4], qc[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { q[e] = q0 + e * RT + tid; qc[e] = min(q[e], m2 - 1); sv[e] = Grow2[qc[e]]; }
+                        int a = 0;
+                        for (; a + 4 <= k; a += 4) {
+                            double2 g[4][4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const double2* ga = reinterpret_cast<const double2*>(p.Gram + (size_t)act[a + u] * m);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) g[u][e] = ga[qc[e]];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const double cf = rv[a + u];
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) { sv[e].x -= cf * g[u][e].x; sv[e].y -= cf * g[u][e].y; }
+                            }
+                        }
+                        for (; a < k; ++a) {
+                            const double cf = rv[a];
+                            const double2* ga = reinterpret_cast<const double2*>(p.Gram + (size_t)act[a] * m);
+                            double2 g[4];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) g[e] = ga[qc[e]];
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) { sv[e].x -= cf * g[e].x; sv[e].y -= cf * g[e].y; }
+                        }
+                        double2 rr[4], cc[4];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { rr[e] = res2[qc[e]]; cc[e] = cs2[qc[e]]; }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (q[e] < m2) {
+                                const double v0 = rr[e].x - t * sv[e].x, v1 = rr[e].y - t * sv[e].y;
+                                res2[q[e]] = double2{v0, v1};
+#pragma unroll
+                                for (int h2 = 0; h2 < 2; ++h2) {
+                                    const double v = h2 ? v1 : v0; const int r = 2 * q[e] + h2;
+                                    if (scan && v > 1e-12 * fmax(1.0, fabs(h2 ? cc[e].y : cc[e].x)) && (fbi < 0 || v > fbest) && r != pp) {
+                                        bool member = false;
+                                        for (int a2 = 0; a2 < k; ++a2) member |= act[a2] == r;
+                                        if (!member) { fbest = v; fbi = r; }
+                                    }
+                                }
+                            }
+                    }
+                } else
                 for (int r0 = 0; r0 < m; r0 += 8 * RT) {
                     double sv[8]; int r[8];
 #pragma unroll
