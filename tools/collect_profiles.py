@@ -42,14 +42,19 @@ def kname(s):
     return re.sub(r"\((PolParams|[A-Za-z]*Params|mpcqp_[a-z_]*\*).*$", "", s)
 
 
+MEDIAN = {}      # (run dir, kernel, counter) -> median over the dispatches (the bench also times the other keep_state mode: the
+                 # mean of FETCH / WRITE mixes the two, the median is the timed mode's)
+
+
 def load(d):
     f = newest(d + "/*/*_counter_collection.csv", required=False)
-    acc = collections.defaultdict(float); cnt = collections.Counter()
+    vals = collections.defaultdict(list)
     if f:
         for r in csv.DictReader(open(f)):
-            k = (kname(r["Kernel_Name"]), r["Counter_Name"])
-            acc[k] += float(r["Counter_Value"]); cnt[k] += 1
-    return {k: (acc[k] / cnt[k], cnt[k]) for k in acc}
+            vals[(kname(r["Kernel_Name"]), r["Counter_Name"])].append(float(r["Counter_Value"]))
+    for k, v in vals.items():
+        MEDIAN[k] = sorted(v)[len(v) // 2]
+    return {k: (sum(v) / len(v), len(v)) for k, v in vals.items()}
 
 
 rows = []
@@ -64,9 +69,10 @@ for run, dirs in sets.items():
         t.update(load(d))
     tables[run] = t
     for (k, c), (v, n) in sorted(t.items()):
-        rows.append((run, k, c, n, v, notes.get(c, "sum over the chip's counter instances")))
+        rows.append((run, k, c, n, v, MEDIAN[(k, c)], notes.get(c, "sum over the chip's counter instances")))
+    MEDIANS = dict(MEDIAN); tables[run + " median"] = {k: (MEDIANS[k], 0) for k in t}; MEDIAN.clear()
 with open(f"{dst}/{tag}_pmc.csv", "w", newline="") as f:
-    w = csv.writer(f); w.writerow(["run", "kernel", "counter", "dispatches", "avg_value", "note"]); w.writerows(rows)
+    w = csv.writer(f); w.writerow(["run", "kernel", "counter", "dispatches", "avg_value", "median_value", "note"]); w.writerows(rows)
 print("wrote", len(rows), "pmc rows")
 
 
@@ -85,10 +91,11 @@ def headline(run, kernel_part, stats_dir, source):
         return None
     k = ks[0]
     g = lambda c: t.get((k, c), (None, 0))[0]
-    out = {"kernel": k, "source": source}
-    if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
-        out["hbm_bytes_per_launch"] = (2.0 * g("FETCH_SIZE") + g("WRITE_SIZE")) * 1024.0
-        out["fetch_kb"], out["write_kb"] = g("FETCH_SIZE"), g("WRITE_SIZE")
+    gm = lambda c: tables[run + " median"].get((k, c), (None, 0))[0]
+    out = {"kernel": k, "source": source + "; HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE, medians over the dispatches (keep_state = 0, the timed mode)"}
+    if gm("FETCH_SIZE") is not None and gm("WRITE_SIZE") is not None:
+        out["hbm_bytes_per_launch"] = (2.0 * gm("FETCH_SIZE") + gm("WRITE_SIZE")) * 1024.0
+        out["fetch_kb"], out["write_kb"] = gm("FETCH_SIZE"), gm("WRITE_SIZE")
     ns = stats_ns(kernel_part, stats_dir)
     if ns and g("SQ_ACTIVE_INST_VALU") is not None:
         cycles = ns * 2.4                                   # shader clock 2.4 GHz
