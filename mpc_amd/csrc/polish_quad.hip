@@ -1342,13 +1342,16 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
 #pragma unroll
             for (int r = 0; r < 4; ++r) cnt[r] += (unsigned long long)((acc[t][r] > hi) | (acc[t][r] < lo)) << sh;
         }
+    // sums over the 16 lanes of an instance = one DPP row: rotations instead of trips through the LDS crossbar (the 8-bit fields
+    // cannot carry into each other: a component has at most 64 rows)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) {
-            const unsigned lo32 = __shfl_xor((unsigned)cnt[r], off), hi32 = __shfl_xor((unsigned)(cnt[r] >> 32), off);
-            cnt[r] += ((unsigned long long)hi32 << 32) | lo32;
-        }
+        int lo = (int)(unsigned)cnt[r], hi = (int)(unsigned)(cnt[r] >> 32);
+        lo += dpp_i<0x128>(lo); hi += dpp_i<0x128>(hi);      // row_ror:8
+        lo += dpp_i<0x124>(lo); hi += dpp_i<0x124>(hi);      // row_ror:4
+        lo += dpp_i<0x122>(lo); hi += dpp_i<0x122>(hi);      // row_ror:2
+        lo += dpp_i<0x121>(lo); hi += dpp_i<0x121>(hi);      // row_ror:1
+        cnt[r] = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
     }
     const int inst0 = blockIdx.x * 64 + wave * 16;
     // rows of the components that x_unc solves

@@ -326,6 +326,10 @@ Layout make_layout(int n, int m) {
     return l;
 }
 
+// ints behind [dense set-up | CH | Gram]: mirror row of every row (m) | mirror pair of every pair (m / 2 + 1) | ok flag, number of
+// working pairs (4) | the working pairs in ascending order (m / 2 + 1)
+inline long mirror_doubles(int m) { return ((long)m + 2 * (m / 2 + 1) + 4 + 1) / 2 + 1; }
+
 struct SharedPtrs { const double *Ps, *Hi, *W0, *Cs, *d, *rn; };
 
 __host__ __device__ inline SharedPtrs shared_ptrs(const double* ws0, int n, int m) {
@@ -365,6 +369,10 @@ struct RowsParams {
     double *x, *z, *obj;
     int *status, *iters;
     int n, m, B, KL, max_steps, refine, pass, warm;
+    const int* mir2;    // per PAIR of rows: the pair holding their negatives (-1: none), valid where *mirok != 0 (rows_mirror_* below)
+    const int* mirok;   // [0] ok, [1] number of working pairs (a pair and the pair of its negatives count once)
+    const int* mlist;   // the working pairs, ascending
+    int res_lds;        // 1: the residual vector lives in LDS behind the other arrays for the length of the iteration (first pass, one workgroup per CU)
 };
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -528,6 +536,15 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     const SharedPtrs s = shared_ptrs(p.ws0, n, m);
     double* c = p.inst + (size_t)qi * p.l.stride;
     double* res = c + p.l.o_res; const double* cs = c + p.l.o_cs; const double* qs = c + p.l.o_qs;
+    double* const res_global = res;
+    if (p.res_lds) {
+        // The residuals are read and rewritten by every step: two of the (k + 4) rows of m doubles a step streams through this
+        // one CU.  When the launch is one workgroup per CU anyway they fit into the LDS the first pass leaves free.
+        double* rl = reinterpret_cast<double*>(smem + (((size_t)((char*)(act + KL) - smem) + 15) & ~(size_t)15));
+        for (int r = tid; r < m; r += RT) rl[r] = res_global[r];
+        res = rl;
+        __syncthreads();
+    }
     const double* xu = c + p.l.o_xu; double* x = c + p.l.o_x; double* t1 = c + p.l.o_t1; double* dv = c + p.l.o_dv;
 
 #ifdef ROWS_PROF
@@ -605,6 +622,8 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     // among the rows it has just rewritten), so only the first one reads the residuals for its own sake
     bool fused = false;
     double fbest = 0.0; int fbi = -1;
+    const bool usem = (m & 1) == 0 && p.mirok[0] != 0;      // uniform: rows stacked with their negatives, pair by pair
+    const int nwork = (m & 1) == 0 ? p.mirok[1] : 0;       // pairs a sweep visits (all m / 2 without mirrors)
     while (status == 0) {
         // the most violated row that is not in the active set
         double best = 0.0; int bi = -1;
@@ -669,14 +688,21 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                     // has in flight: with 8-byte loads and one active row at a time, 64 KB -- 25-40 GB/s at the latency of a
                     // miss, 30 us per step at full size.  Here: 16-byte loads (row pairs; rows of an even m are 16-byte aligned)
                     // and FOUR active rows' loads issued before the first is used: 256 KB in flight.  Same sums in the same order.
-                    const int m2 = m >> 1;
                     const double2* Grow2 = reinterpret_cast<const double2*>(Grow);
                     double2* res2 = reinterpret_cast<double2*>(res);
-                    const double2* cs2 = reinterpret_cast<const double2*>(cs);
-                    for (int q0 = 0; q0 < m2; q0 += 4 * RT) {
-                        double2 sv[4]; int q[4], qc[4];
+                    // (over the working pairs: of a pair and the pair of its negatives the one with the lower index reads Gram and
+                    // updates both)
+                    for (int i0 = 0; i0 < nwork; i0 += 4 * RT) {
+                        double2 sv[4]; int q[4], qa[4], mq[4]; bool work[4];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) { q[e] = q0 + e * RT + tid; qc[e] = min(q[e], m2 - 1); sv[e] = Grow2[qc[e]]; }
+                        for (int e = 0; e < 4; ++e) {
+                            const int i = i0 + e * RT + tid;
+                            work[e] = i < nwork;
+                            q[e] = p.mlist[min(i, nwork - 1)];
+                            mq[e] = usem ? p.mir2[q[e]] : -1;
+                            qa[e] = q[e];
+                            sv[e] = Grow2[qa[e]];
+                        }
                         int a = 0;
                         for (; a + 4 <= k; a += 4) {
                             double2 g[4][4];
@@ -684,7 +710,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                             for (int u = 0; u < 4; ++u) {
                                 const double2* ga = reinterpret_cast<const double2*>(p.Gram + (size_t)act[a + u] * m);
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) g[u][e] = ga[qc[e]];
+                                for (int e = 0; e < 4; ++e) g[u][e] = ga[qa[e]];
                             }
 #pragma unroll
                             for (int u = 0; u < 4; ++u) {
@@ -698,26 +724,32 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                             const double2* ga = reinterpret_cast<const double2*>(p.Gram + (size_t)act[a] * m);
                             double2 g[4];
 #pragma unroll
-                            for (int e = 0; e < 4; ++e) g[e] = ga[qc[e]];
+                            for (int e = 0; e < 4; ++e) g[e] = ga[qa[e]];
 #pragma unroll
                             for (int e = 0; e < 4; ++e) { sv[e].x -= cf * g[e].x; sv[e].y -= cf * g[e].y; }
                         }
-                        double2 rr[4], cc[4];
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { rr[e] = res2[qc[e]]; cc[e] = cs2[qc[e]]; }
+                        // the rows this thread has just rewritten are its candidates for the next scan
+                        auto cand = [&](double v, int r) {
+                            // (the row's tolerance 1e-12 max(1, |cs_r|) is looked up only for a row that passes the others:
+                            // a handful per sweep instead of one more stream of m doubles)
+                            if (scan && v > 1e-12 && (fbi < 0 || v > fbest) && r != pp && v > 1e-12 * fabs(cs[r])) {
+                                bool member = false;
+                                for (int a2 = 0; a2 < k; ++a2) member |= act[a2] == r;
+                                if (!member) { fbest = v; fbi = r; }
+                            }
+                        };
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (q[e] < m2) {
-                                const double v0 = rr[e].x - t * sv[e].x, v1 = rr[e].y - t * sv[e].y;
+                            if (work[e]) {
+                                const double2 rr = res2[q[e]];
+                                const double v0 = rr.x - t * sv[e].x, v1 = rr.y - t * sv[e].y;
                                 res2[q[e]] = double2{v0, v1};
-#pragma unroll
-                                for (int h2 = 0; h2 < 2; ++h2) {
-                                    const double v = h2 ? v1 : v0; const int r = 2 * q[e] + h2;
-                                    if (scan && v > 1e-12 * fmax(1.0, fabs(h2 ? cc[e].y : cc[e].x)) && (fbi < 0 || v > fbest) && r != pp) {
-                                        bool member = false;
-                                        for (int a2 = 0; a2 < k; ++a2) member |= act[a2] == r;
-                                        if (!member) { fbest = v; fbi = r; }
-                                    }
+                                cand(v0, 2 * q[e]); cand(v1, 2 * q[e] + 1);
+                                if (mq[e] >= 0) {           // their negatives: the same update with the other sign
+                                    const double2 rm = res2[mq[e]];
+                                    const double w0 = rm.x + t * sv[e].x, w1 = rm.y + t * sv[e].y;
+                                    res2[mq[e]] = double2{w0, w1};
+                                    cand(w0, 2 * mq[e]); cand(w1, 2 * mq[e] + 1);
                                 }
                             }
                     }
@@ -760,6 +792,7 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
                         __syncthreads();
                         for (int a = tid; a < k; a += RT) { sact[2 + a] = act[a]; slam[a] = lam[a]; }
                         if (tid == 0) { sact[2 + k] = pp; slam[k] = accl; sact[0] = k + 1; sact[1] = steps; }
+                        if (p.res_lds) for (int r = tid; r < m; r += RT) res_global[r] = res[r];      // the second pass reads them from memory
                         handed_over = true;
                     }
                     break;
@@ -914,6 +947,65 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
     }
 }
 
+// ---- rows that come with their negatives -----------------------------------------------------------------------------
+// The reference stacks every two-sided bound as a row and its negative (LaunchPlannerQPFormulation.py:96-118: +-I, +-rows of
+// the prediction matrix), so half of Gram's columns are the other half with the sign flipped: Gram[a][r'] = -Gram[a][r]
+// bit for bit when Cs[r'] = -Cs[r] (same products, same order).  The sweep of a step then needs only ONE of the two
+// columns: half the bytes of what a step streams.  Found from Gram itself, so any caller of the set-up gets it:
+// Cs[r'] = -Cs[r]  <=>  (Cs[r] + Cs[r'])' Hi (Cs[r] + Cs[r']) = G_rr + 2 G_rr' + G_r'r' = 0 (Hi positive definite), tested
+// as G_rr' == -G_rr and G_r'r' == G_rr exactly, then confirmed on the two rows of Cs entry by entry -- a pair that misses by
+// rounding is simply not used.
+__global__ __launch_bounds__(256) void rows_mirror_find_kernel(const double* Gram, const double* Cs, int n, int m, int* mir) {
+    __shared__ int best, differs;
+    const int r = blockIdx.x;
+    if (threadIdx.x == 0) { best = 0x7fffffff; differs = 0; }
+    __syncthreads();
+    const double* g = Gram + (size_t)r * m;
+    const double drr = g[r];
+    if (drr > 0.0)
+        for (int c = threadIdx.x; c < m; c += 256)
+            if (c != r && g[c] == -drr && Gram[(size_t)c * m + c] == drr) atomicMin(&best, c);
+    __syncthreads();
+    const int c = best;
+    if (c != 0x7fffffff)        // the candidate's row itself, entry by entry: nothing is taken on the strength of two equal sums
+        for (int j = threadIdx.x; j < n; j += 256)
+            if (Cs[(size_t)c * n + j] != -Cs[(size_t)r * n + j]) differs = 1;
+    __syncthreads();
+    if (threadIdx.x == 0) mir[r] = (c == 0x7fffffff || differs) ? -1 : c;
+}
+// the sweep works on row PAIRS (16-byte loads): usable only if mirrors pair up the same way -- (2q, 2q+1) <-> (2q', 2q'+1),
+// mutually -- for every pair; otherwise *ok = 0 and the sweep reads every column
+__global__ __launch_bounds__(256) void rows_mirror_pairs_kernel(const int* mir, int m, int* mir2, int* ok) {
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= m / 2) return;
+    const int a = mir[2 * q], b = mir[2 * q + 1];
+    const bool none = a < 0 && b < 0;
+    const bool pair = a >= 0 && (a & 1) == 0 && b == a + 1 && mir[a] == 2 * q && mir[a + 1] == 2 * q + 1;
+    mir2[q] = pair ? a / 2 : -1;
+    if (!none && !pair) atomicAnd(ok, 0);
+}
+
+// the pairs a sweep has to visit (every pair without a mirror, and of two mirrored pairs the lower one), ascending, and
+// their number in okc[1]: one workgroup, every thread a contiguous run of pairs
+__global__ __launch_bounds__(1024) void rows_mirror_list_kernel(const int* mir2, int m2, int* okc, int* list) {
+    __shared__ int cnt[1024];
+    const int tid = threadIdx.x, per = (m2 + 1023) / 1024, lo = min(tid * per, m2), hi = min(lo + per, m2);
+    const bool usem = okc[0] != 0;
+    int c = 0;
+    for (int q = lo; q < hi; ++q) c += !(usem && mir2[q] >= 0 && mir2[q] < q);
+    cnt[tid] = c;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+        const int v = tid >= s ? cnt[tid - s] : 0;
+        __syncthreads();
+        cnt[tid] += v;
+        __syncthreads();
+    }
+    int o = cnt[tid] - c;
+    for (int q = lo; q < hi; ++q) if (!(usem && mir2[q] >= 0 && mir2[q] < q)) list[o++] = q;
+    if (tid == 1023) okc[1] = cnt[1023];
+}
+
 // out = max_i sum_j |E_ij - delta_ij| (one wave per row; non-negative doubles order like their bit patterns)
 __global__ __launch_bounds__(256) void inv_resid_kernel(const double* E, int n, double* out) {
     const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -945,7 +1037,7 @@ long mpcqp_rows_workspace(int n, int m, long* per_instance) {
     if (n < 1 || m < 1) return 0;
     const Layout l = make_layout(n, m);
     if (per_instance) *per_instance = l.stride;
-    return l.nd0 + (long)m * n + (long)m * m;
+    return l.nd0 + (long)m * n + (long)m * m + mirror_doubles(m);
 }
 
 int mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double* G, double* shared_ws, int* int_ws,
@@ -963,6 +1055,17 @@ int mpcqp_rows_setup(int device_id, int n, int m, const double* P, const double*
     if (rc != MPCQP_OK) return rc;
     rc = launch_gemm_nt(CH, n, s.Cs, n, Gram, m, m, m, n, 1.0, 0.0, st);            // Gram = CH Cs'
     if (rc != MPCQP_OK) return rc;
+    {   // rows stacked with their negatives (one more pass over Gram, once per model)
+        int* mir = reinterpret_cast<int*>(Gram + (size_t)m * m);
+        int* mir2 = mir + m;
+        int* ok = mir2 + m / 2 + 1;
+        const int one = (m & 1) ? 0 : 1;
+        if (hipMemcpyAsync(ok, &one, sizeof(int), hipMemcpyHostToDevice, st) != hipSuccess) return MPCQP_EHIP;
+        hipLaunchKernelGGL(rows_mirror_find_kernel, dim3(m), dim3(256), 0, st, Gram, s.Cs, n, m, mir);
+        if (m >= 2) hipLaunchKernelGGL(rows_mirror_pairs_kernel, dim3(ceil_div(m / 2, 256)), dim3(256), 0, st, mir, m, mir2, ok);
+        hipLaunchKernelGGL(rows_mirror_list_kernel, dim3(1), dim3(1024), 0, st, mir2, m / 2, ok, ok + 4);
+        if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
+    }
     // eps = |I - Ps Hi|_inf into the third entry of QP 0's W block (beside sigma and the status): what the solve's tail
     // needs to certify stationarity without a matvec.  The product goes to QP 0's T block, free once the inverse exists
     double* W0 = shared_ws + (size_t)2 * n * n;
@@ -1013,21 +1116,34 @@ static int rows_solve_impl(int device_id, int batch, int n, int m, const double*
     r.x = x; r.z = z; r.obj = obj; r.status = status; r.iters = iters;
     r.n = n; r.m = m; r.B = batch; r.max_steps = 20 * (n + m) + 100;
     r.warm = warm ? 1 : 0;
+    r.mir2 = reinterpret_cast<const int*>(Gram + (size_t)m * m) + m; r.mirok = r.mir2 + m / 2 + 1; r.mlist = r.mirok + 4;
     r.refine = 1;       // Hi is the exact-arithmetic inverse here (no proximal term): one round squares its rounding error
     auto lds_of = [&](int KL) {
         const size_t tri = (size_t)KL * (KL + 1) / 2;
         return (tri + (tri & 1) + 4 * (size_t)KL + n + (n & 1) + RT) * sizeof(double) + (size_t)KL * sizeof(int);
     };
     const int KL1 = rows_kl1(n, m), KL2 = rows_kl2(n, m);
-    const size_t lds1 = lds_of(KL1), lds2 = lds_of(KL2);
+    size_t lds1 = lds_of(KL1);
+    const size_t lds2 = lds_of(KL2);
     if (lds1 > 160 * 1024) return MPCQP_ENOTIMPL;
+    // residuals in LDS: only when the launch is one round of one workgroup per CU either way (a larger batch wants the second
+    // workgroup per CU more than the shorter sweep) and they fit behind the first pass's arrays
+    static int ncu_of[64] = {};         // CUs per device, asked once (0: not yet; a failed query leaves the residuals in memory)
+    if (device_id < 64 && ncu_of[device_id] == 0) {
+        int v = 0;
+        ncu_of[device_id] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ? v : -1;
+    }
+    const int ncu = device_id < 64 ? ncu_of[device_id] : -1;
+    const size_t lds1r = ((lds1 + 15) & ~(size_t)15) + (size_t)m * sizeof(double);
+    r.res_lds = (batch <= ncu && lds1r <= 160 * 1024) ? 1 : 0;
+    if (r.res_lds) lds1 = lds1r;
     const bool second = KL2 > KL1 && lds2 <= 160 * 1024;
-    if (ensure_dyn_lds(device_id, reinterpret_cast<const void*>(&rows_qp_kernel), second ? lds2 : lds1) != hipSuccess) return MPCQP_EHIP;
+    if (ensure_dyn_lds(device_id, reinterpret_cast<const void*>(&rows_qp_kernel), std::max(lds1, second ? lds2 : lds1)) != hipSuccess) return MPCQP_EHIP;
     r.KL = KL1; r.pass = 1;
     hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds1, st, r);
     if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
     if (second) {       // instances whose active set outgrew the first pass continue where they stopped; the others return at once
-        r.KL = KL2; r.pass = 2;
+        r.KL = KL2; r.pass = 2; r.res_lds = 0;
         hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds2, st, r);
     }
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;

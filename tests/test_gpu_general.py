@@ -318,6 +318,70 @@ def test_rows_kernel_tail_refines_when_the_inverse_is_not_accurate_enough(cond):
     assert nact >= B
 
 
+@pytest.mark.parametrize("blocks,used", [([(10, True), (16, True), (7, False)], True),     # even blocks with their negatives + one-sided rows
+                                         ([(9, True), (12, True)], False),                # an odd block: negatives do not pair up two by two
+                                         ([(14, False)], True)])                           # no negatives at all: every pair is visited
+def test_rows_stacked_with_their_negatives_are_swept_once(blocks, used):
+    """The reference stacks two-sided bounds as a row and its negative (LaunchPlannerQPFormulation.py:96-118).  The set-up of the
+    constraint-space kernel finds such pairs in the dual Hessian (Gram[a][r'] = -Gram[a][r]), and a step's residual sweep then
+    reads one column of the two.  Detection (the flag, the number of row pairs a sweep visits) and the answers against the
+    oracle, with the shortcut in use, refused (pairs misaligned) and without any mirrored row."""
+    import ctypes as C
+    import torch
+    from mpc_amd import _lib
+    from oracle.qp_oracle import solve_qp
+    lib = _lib.load()
+    rng = np.random.default_rng(23)
+    n, B = 30, 5
+    parts, hs, mirrored = [], [], 0
+    for rows, both in blocks:
+        A = rng.standard_normal((rows, n))
+        parts.append(A); hs.append(rng.uniform(0.05, 0.4, (B, rows)))
+        if both:
+            parts.append(-A); hs.append(rng.uniform(0.05, 0.4, (B, rows))); mirrored += rows
+    G = np.vstack(parts); h = np.hstack(hs)
+    m = G.shape[0]
+    if m & 1:
+        G = np.vstack([G, rng.standard_normal((1, n))]); h = np.hstack([h, rng.uniform(0.05, 0.4, (B, 1))]); m += 1
+    Qo, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    P = Qo @ np.diag(np.logspace(0, 2, n)) @ Qo.T
+    P = 0.5 * (P + P.T)
+    q = rng.standard_normal((B, n)) * 4.0
+    dev = torch.device("cuda:0")
+    t = lambda a, dt=torch.float64: torch.as_tensor(a, dtype=dt, device=dev).contiguous()
+    per = C.c_long(0)
+    nsh = lib.mpcqp_rows_workspace(n, m, C.byref(per))
+    sh = torch.zeros(nsh, dtype=torch.float64, device=dev)
+    iw = torch.zeros(n, dtype=torch.int32, device=dev)
+    inst = torch.zeros(B * per.value, dtype=torch.float64, device=dev)
+    Pt, Gt, qt, ht = t(P), t(G), t(q), t(h)
+    x = torch.zeros((B, n), dtype=torch.float64, device=dev); z = torch.zeros((B, m), dtype=torch.float64, device=dev)
+    obj = torch.zeros(B, dtype=torch.float64, device=dev)
+    st = torch.full((B,), -1, dtype=torch.int32, device=dev); it = torch.zeros(B, dtype=torch.int32, device=dev)
+    ptr = lambda a: C.c_void_p(a.data_ptr())
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    assert lib.mpcqp_rows_setup(0, n, m, ptr(Pt), ptr(Gt), ptr(sh), ptr(iw), stream) == 0
+    assert lib.mpcqp_rows_solve(0, B, n, m, ptr(qt), ptr(ht), ptr(x), ptr(z), ptr(obj), ptr(st), ptr(it), ptr(sh), ptr(inst),
+                                stream) == 0
+    torch.cuda.synchronize()
+    # the ints behind Gram: mirror of every row (m) | mirror pair of every pair (m/2 + 1) | ok, working pairs, -, - | list
+    nd = ((m + 2 * (m // 2 + 1) + 4 + 1) // 2 + 1)
+    blk = sh[nsh - nd:].view(torch.int32).cpu().numpy()
+    mir, ok, nwork = blk[:m], int(blk[m + m // 2 + 1]), int(blk[m + m // 2 + 2])
+    assert int((mir >= 0).sum()) == 2 * mirrored          # every stacked row found its negative, nothing else did
+    assert ok == (1 if used else 0)
+    assert nwork == (m // 2 - mirrored // 2 if used else m // 2)
+    xs, zs, os_, ss = x.cpu().numpy(), z.cpu().numpy(), obj.cpu().numpy(), st.cpu().numpy()
+    for i in range(B):
+        s = solve_qp(P, q[i], G, h[i])
+        assert s["status"] == "optimal" and ss[i] == 0, i
+        assert np.abs(xs[i] - s["x"]).max() <= 1e-6 * max(1.0, np.abs(s["x"]).max()), i
+        assert abs(os_[i] - s["primal objective"]) <= 1e-8 * max(abs(s["primal objective"]), 1e-12), i
+        assert (G @ xs[i] - h[i]).max() <= 1e-9
+        assert (zs[i] >= -1e-12).all()
+    assert int((zs > 0).sum()) >= B
+
+
 def test_warm_start_of_the_constraint_space_kernel_lands_on_the_cold_solution():
     """warm_start in the general-constraint mode (mpcqp_rows_solve_mpc_warm): the solve starts from the working set the previous
     solve of the same batch ended with.  (a) the same data again: confirmed without a step; (b) nearby data: the same minimiser
