@@ -43,6 +43,9 @@ struct GemmParams {
     // epilogue: C = (alpha acc + bias[j]) (* or /) cscale[j] + beta Cin   (bias, cscale per column; NULL = none; Cin NULL = C)
     const double *bias, *cscale, *Cin;
     int cdiv;
+    // gemm_nt_lds_kernel only: column j of C is the product with row 2 bpairs[j / 2] + (j & 1) of B, for the first 2 bcount[0]
+    // columns (the count lives on the device: workgroups beyond it leave at once); nullptr: column j <-> row j
+    const int *bpairs, *bcount;
 };
 
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams g) {
@@ -131,6 +134,8 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams g) {
     const int col = lane & 15, kq = lane >> 4;
     const int bi = blockIdx.y * 64, bj = blockIdx.x * 64;
     const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
+    const int N = g.bpairs ? min(g.N, 2 * g.bcount[0]) : g.N;
+    if (bj >= N) return;                            // uniform over the workgroup, before any barrier
     d4 acc[2][2];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -142,7 +147,8 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams g) {
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
         ga[u] = g.A + (size_t)min(bi + sr + 16 * u, g.M - 1) * g.lda + sc;      // rows beyond the matrix: a copy of the last row,
-        gb[u] = g.B + (size_t)min(bj + sr + 16 * u, g.N - 1) * g.ldb + sc;      // whose products are never stored
+        const int j = min(bj + sr + 16 * u, N - 1);                             // whose products are never stored
+        gb[u] = g.B + (size_t)(g.bpairs ? 2 * g.bpairs[j >> 1] + (j & 1) : j) * g.ldb + sc;
     }
     double2 ra[4], rb[4];
     auto fetch = [&](int k0) {
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_nt_lds_kernel(GemmParams g) {
 #pragma unroll
             for (int r4 = 0; r4 < 4; ++r4) {
                 const int i = bi + wi + 16 * ti + kq + 4 * r4, j = bj + wj + 16 * tj + col;
-                if (i < g.M && j < g.N) {
+                if (i < g.M && j < N) {
                     double* c = g.C + (size_t)i * g.ldc + j;
                     double v = g.alpha * acc[ti][tj][r4];
                     if (g.bias) v += g.bias[j];
@@ -288,7 +294,7 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
                    double alpha, double beta, hipStream_t st, const double* bias = nullptr, const double* cscale = nullptr,
                    int cdiv = 0, const double* Cin = nullptr) {
     GemmParams g;
-    g.bias = bias; g.cscale = cscale; g.cdiv = cdiv; g.Cin = Cin;
+    g.bias = bias; g.cscale = cscale; g.cdiv = cdiv; g.Cin = Cin; g.bpairs = nullptr; g.bcount = nullptr;
     g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.beta = beta;
     g.vec = (lda % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0);
     if ((long)ceil_div(N, 64) * ceil_div(M, 64) < 128 && K >= 256)      // few tiles, long K: split K over the waves
@@ -298,6 +304,19 @@ int launch_gemm_nt(const double* A, long lda, const double* B, long ldb, double*
     else
         hipLaunchKernelGGL(gemm_nt_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+// C (M x 2 count) = A (M x K) Bsel' where Bsel takes the row pairs bpairs[0 .. count) of B (count on the device, at most N / 2);
+// false if the shapes do not fit the LDS-staged kernel (the caller then forms the whole product)
+bool launch_gemm_nt_pairs(const double* A, long lda, const double* B, long ldb, double* C, long ldc, int M, int N, int K,
+                          const int* bpairs, const int* bcount, hipStream_t st) {
+    const bool vec = lda % 2 == 0 && ldb % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(B) % 16 == 0;
+    if (!(vec && K % 2 == 0 && K >= 64 && M >= 64 && N >= 64 && N % 2 == 0)) return false;
+    GemmParams g;
+    g.bias = nullptr; g.cscale = nullptr; g.cdiv = 0; g.Cin = nullptr; g.bpairs = bpairs; g.bcount = bcount;
+    g.A = A; g.B = B; g.C = C; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.alpha = 1.0; g.beta = 0.0; g.vec = 1;
+    hipLaunchKernelGGL(gemm_nt_lds_kernel, dim3(ceil_div(N, 64), ceil_div(M, 64)), dim3(256), 0, st, g);
+    return true;
 }
 
 // ---- per-instance scaling of (q, h) ------------------------------------------------------------------------------------
@@ -372,6 +391,8 @@ struct RowsParams {
     const int* mir2;    // per PAIR of rows: the pair holding their negatives (-1: none), valid where *mirok != 0 (rows_mirror_* below)
     const int* mirok;   // [0] ok, [1] number of working pairs (a pair and the pair of its negatives count once)
     const int* mlist;   // the working pairs, ascending
+    int res_compact;    // with res_lds: the instance's residual block holds the products Xu Cs' of the working pairs only, in list order
+                        // (launch_gemm_nt_pairs); the rows' residuals -- and their negatives' -- are formed while they are loaded
     int res_lds;        // 1: the residual vector lives in LDS behind the other arrays for the length of the iteration (first pass, one workgroup per CU)
 };
 
@@ -541,6 +562,20 @@ __global__ __launch_bounds__(RT) void rows_qp_kernel(RowsParams p) {
         // The residuals are read and rewritten by every step: two of the (k + 4) rows of m doubles a step streams through this
         // one CU.  When the launch is one workgroup per CU anyway they fit into the LDS the first pass leaves free.
         double* rl = reinterpret_cast<double*>(smem + (((size_t)((char*)(act + KL) - smem) + 15) & ~(size_t)15));
+        if (p.res_compact) {
+            // res_r = (Cs xu)_r - cs_r; the row stacked as the negative of r: res_r' = -(Cs xu)_r - cs_r'
+            const int nw = p.mirok[1]; const bool um = p.mirok[0] != 0;
+            const double2* pr2 = reinterpret_cast<const double2*>(res_global);
+            const double2* cs2 = reinterpret_cast<const double2*>(cs);
+            double2* rl2 = reinterpret_cast<double2*>(rl);
+            for (int i = tid; i < nw; i += RT) {
+                const int q = p.mlist[i];
+                const double2 v = pr2[i], c0 = cs2[q];
+                rl2[q] = double2{v.x - c0.x, v.y - c0.y};
+                const int mq = um ? p.mir2[q] : -1;
+                if (mq >= 0) { const double2 c1 = cs2[mq]; rl2[mq] = double2{-v.x - c1.x, -v.y - c1.y}; }
+            }
+        } else
         for (int r = tid; r < m; r += RT) rl[r] = res_global[r];
         res = rl;
         __syncthreads();
@@ -1104,13 +1139,6 @@ static int rows_solve_impl(int device_id, int batch, int n, int m, const double*
         hipLaunchKernelGGL(rows_prep_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, st, pp);
         if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
     }
-    // xu = -Hi qs ;  res = Cs xu - cs   (both over the whole batch: the shared matrices are read once, not once per QP)
-    rc = launch_gemm_nt(instance_ws + l.o_qs, l.stride, s.Hi, n, instance_ws + l.o_xu, l.stride, batch, n, n, -1.0, 0.0, st);
-    if (rc != MPCQP_OK) return rc;
-    rc = launch_gemm_nt(instance_ws + l.o_xu, l.stride, s.Cs, n, instance_ws + l.o_res, l.stride, batch, m, n, 1.0, -1.0, st,
-                        nullptr, nullptr, 0, instance_ws + l.o_cs);
-    if (rc != MPCQP_OK) return rc;
-
     RowsParams r;
     r.ws0 = shared_ws; r.CH = CH; r.Gram = Gram; r.inst = instance_ws; r.l = l;
     r.x = x; r.z = z; r.obj = obj; r.status = status; r.iters = iters;
@@ -1137,13 +1165,26 @@ static int rows_solve_impl(int device_id, int batch, int n, int m, const double*
     const size_t lds1r = ((lds1 + 15) & ~(size_t)15) + (size_t)m * sizeof(double);
     r.res_lds = (batch <= ncu && lds1r <= 160 * 1024) ? 1 : 0;
     if (r.res_lds) lds1 = lds1r;
+    // xu = -Hi qs ;  res = Cs xu - cs   (both over the whole batch: the shared matrices are read once, not once per QP)
+    rc = launch_gemm_nt(instance_ws + l.o_qs, l.stride, s.Hi, n, instance_ws + l.o_xu, l.stride, batch, n, n, -1.0, 0.0, st);
+    if (rc != MPCQP_OK) return rc;
+    // with the residuals loaded into LDS by the kernel itself, the product is formed for the working row pairs only (rows
+    // stacked with their negatives: half of it) and "- cs" moves into that load
+    r.res_compact = (r.res_lds && launch_gemm_nt_pairs(instance_ws + l.o_xu, l.stride, s.Cs, n, instance_ws + l.o_res, l.stride, batch, m,
+                                                       n, r.mlist, r.mirok + 1, st)) ? 1 : 0;
+    if (!r.res_compact) {
+        rc = launch_gemm_nt(instance_ws + l.o_xu, l.stride, s.Cs, n, instance_ws + l.o_res, l.stride, batch, m, n, 1.0, -1.0, st,
+                            nullptr, nullptr, 0, instance_ws + l.o_cs);
+        if (rc != MPCQP_OK) return rc;
+    }
+    if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
     const bool second = KL2 > KL1 && lds2 <= 160 * 1024;
     if (ensure_dyn_lds(device_id, reinterpret_cast<const void*>(&rows_qp_kernel), std::max(lds1, second ? lds2 : lds1)) != hipSuccess) return MPCQP_EHIP;
     r.KL = KL1; r.pass = 1;
     hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds1, st, r);
     if (hipGetLastError() != hipSuccess) return MPCQP_EHIP;
     if (second) {       // instances whose active set outgrew the first pass continue where they stopped; the others return at once
-        r.KL = KL2; r.pass = 2; r.res_lds = 0;
+        r.KL = KL2; r.pass = 2; r.res_lds = 0; r.res_compact = 0;
         hipLaunchKernelGGL(rows_qp_kernel, dim3(batch), dim3(RT), lds2, st, r);
     }
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
