@@ -217,7 +217,8 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream) {
     hipStream_t st = static_cast<hipStream_t>(stream);
     h->sp_C = 0;            // the component split belongs to the factorisation it was found in (split_setup below)
     // state-box / polytopic rows, or more inputs than the box kernels hold: the general-constraint path (general.hip)
-    if (h->g_xmin || h->g_C || h->g_path == 2 || !admm_shared_box_supported(h->NT, h->S)) return factor_general(h, st);
+    // (more than 64 states: the box kernels stage x0 in 64 lanes; the general path forms q = F x0 + f0 with a GEMM of any depth)
+    if (h->g_xmin || h->g_C || h->g_path == 2 || !admm_shared_box_supported(h->NT, h->S) || h->dims.nx > 64) return factor_general(h, st);
     if (h->general) general_free(h);
     if (h->dims.n_models > 1) TRY(launch_factor_batch(h, st, !(opts && opts->no_sync)));      // one model per instance: active-set path only
     else TRY(launch_factor(h, opts ? opts->rho : 0.0, st));

@@ -21,7 +21,7 @@ namespace {
 
 struct AsmParams {
     const double *A, *B, *Q, *R, *P, *xref, *uref;
-    int rows_in_lds, ab_in_lds;
+    int rows_in_lds, ab_in_lds, q_in_lds;
     long xref_stride, uref_stride;       // doubles between the references of consecutive models (0: shared)
     double *Gam, *QG, *Phi, *H, *F, *f0;
     int nx, nu, N, n, p, tv;
@@ -51,12 +51,12 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     double* rowP = reinterpret_cast<double*>(smem);     // 2 x (nx, nx)
     double* rowG = rowP + 2 * nx * nx;                  // 2 x (nx, n) ping-pong
     double* sQ = rowG + (a.rows_in_lds ? 2 * nx * n : 0);   // Q, P (nx, nx) each
-    double* sA = sQ + 2 * nx * nx;                      // the model's A_k, B_k (a.ab_in_lds): the rollout is a chain of
+    double* sA = sQ + (a.q_in_lds ? 2 * nx * nx : 0);   // the model's A_k, B_k (a.ab_in_lds): the rollout is a chain of
     double* sB = sA + (a.tv ? N : 1) * nx * nx;         // N dependent steps, so nothing in it should wait on global memory
     const int tid = threadIdx.x;
     const int Y = gridDim.y, y = blockIdx.y;
     if (a.phases & 1) {
-    for (int i = tid; i < nx * nx; i += 256) { sQ[i] = a.Q[i]; sQ[nx * nx + i] = a.P[i]; }
+    if (a.q_in_lds) for (int i = tid; i < nx * nx; i += 256) { sQ[i] = a.Q[i]; sQ[nx * nx + i] = a.P[i]; }
     if (a.ab_in_lds) {
         for (int i = tid; i < (int)strideA; i += 256) sA[i] = Am[i];
         for (int i = tid; i < (int)strideB; i += 256) sB[i] = Bm[i];
@@ -77,7 +77,8 @@ __global__ __launch_bounds__(256) void assemble_kernel(AsmParams a) {
     for (int k = 0; k < N; ++k) {
         const double* Ak = (a.ab_in_lds ? sA : Am) + (a.tv ? (size_t)k * nx * nx : 0);
         const double* Bk = (a.ab_in_lds ? sB : Bm) + (a.tv ? (size_t)k * nx * nu : 0);
-        const double* Qk = (k == N - 1) ? sQ + nx * nx : sQ;
+        // (more than 71 states: the weights stay in memory -- the Phi ping-pong alone then takes most of the LDS)
+        const double* Qk = a.q_in_lds ? ((k == N - 1) ? sQ + nx * nx : sQ) : ((k == N - 1) ? a.P : a.Q);
         const double* gin = a.rows_in_lds ? rowG + (k & 1) * nx * n : Gam + (size_t)(k > 0 ? k - 1 : 0) * nx * n;
         double* gout = a.rows_in_lds ? rowG + ((k + 1) & 1) * nx * n : Gam + (size_t)k * nx * n;
         const double* pin = rowP + (k & 1) * nx * nx;
@@ -478,7 +479,7 @@ static int launch_assemble_wave(mpcqp_handle h, hipStream_t st) {
     a.xref_stride = h->xref_stride; a.uref_stride = h->uref_stride;
     a.Gam = nullptr; a.QG = nullptr; a.Phi = h->Phi; a.H = h->H; a.F = h->F; a.f0 = h->f0;
     a.nx = nx; a.nu = nu; a.N = N; a.n = h->n; a.p = h->p; a.tv = h->dims.time_varying;
-    a.rows_in_lds = 0; a.ab_in_lds = 0; a.phases = 0;
+    a.rows_in_lds = 0; a.ab_in_lds = 0; a.q_in_lds = 0; a.phases = 0;
     int rc = MPCQP_OK;
     switch (nx) {
         case 1: rc = launch_assemble_wave_nx<1>(h, a, lds, st); break;
@@ -510,7 +511,9 @@ int launch_assemble(mpcqp_handle h, hipStream_t st, bool with_gamma, bool gamma_
     a.xref_stride = h->xref_stride; a.uref_stride = h->uref_stride;
     a.Gam = h->Gam; a.QG = h->QG; a.Phi = h->Phi; a.H = h->H; a.F = h->F; a.f0 = h->f0;
     a.nx = h->dims.nx; a.nu = h->dims.nu; a.N = h->dims.N; a.n = h->n; a.p = h->p; a.tv = h->dims.time_varying;
-    const size_t fixed = (size_t)(4 * a.nx * a.nx) * sizeof(double);        // Phi ping-pong + Q, P
+    const size_t pp = (size_t)(2 * a.nx * a.nx) * sizeof(double);           // Phi ping-pong; Q, P beside it while they fit
+    a.q_in_lds = 2 * pp <= 160 * 1024;
+    const size_t fixed = a.q_in_lds ? 2 * pp : pp;
     const size_t rows = (size_t)(2 * a.nx * a.n) * sizeof(double);
     const size_t ab = (size_t)(a.tv ? a.N : 1) * a.nx * (a.nx + a.nu) * sizeof(double);
     a.rows_in_lds = fixed + rows <= 160 * 1024;

@@ -318,6 +318,32 @@ def test_rows_kernel_tail_refines_when_the_inverse_is_not_accurate_enough(cond):
     assert nact >= B
 
 
+@pytest.mark.parametrize("nx,nu,N", [(72, 2, 6), (100, 3, 5), (65, 1, 20)])
+def test_more_than_64_states_take_the_general_route(nx, nu, N):
+    """The box kernels stage x0 in 64 lanes; a model with more states is routed to the general-constraint kernels inside
+    mpcqp_factor (q = F x0 + f0 by a GEMM of any depth), and the assembly keeps Q, P in memory once the Phi ping-pong alone
+    fills the LDS (nx > 71).  Round 2 raised NotImplementedError here.  Input box only, against the oracle."""
+    from mpc_amd.planner import Planner
+    from oracle import mpc_oracle as mo
+    from oracle.qp_oracle import solve_box_qp
+    rng = np.random.default_rng(nx)
+    A = 0.9 * np.eye(nx) + 0.1 * rng.standard_normal((nx, nx)) / np.sqrt(nx)
+    B = rng.standard_normal((nx, nu)) / np.sqrt(nx)
+    prob = dict(nx=nx, nu=nu, N=N, A=A, B=B, Q=np.eye(nx), R=0.1 * np.eye(nu), P=2.0 * np.eye(nx),
+                u_min=-0.3 * np.ones(nu), u_max=0.2 * np.ones(nu), x0=rng.uniform(-1, 1, (40, nx)))
+    pl = Planner(nx, nu, N).set_model(A, B).set_cost(prob["Q"], prob["R"], prob["P"]).set_constraints(prob["u_min"], prob["u_max"])
+    U = pl.solve(prob["x0"]).cpu().numpy().reshape(40, -1)
+    assert (pl.info.status.cpu().numpy() == 0).all()
+    H, F, f0 = mo.condense(prob)
+    lb = np.tile(prob["u_min"], N); ub = np.tile(prob["u_max"], N)
+    obj = pl.info.obj.cpu().numpy()
+    for i in range(0, 40, 4):
+        s = solve_box_qp(H, F @ prob["x0"][i] + f0, lb, ub)
+        assert np.abs(U[i] - s["x"]).max() <= 1e-6 * max(1.0, np.abs(s["x"]).max()), i
+        assert abs(obj[i] - s["primal objective"]) <= 1e-8 * max(abs(s["primal objective"]), 1e-12), i
+    assert int(((U >= ub - 1e-9) | (U <= lb + 1e-9)).sum()) > 40          # the bounds do bind
+
+
 @pytest.mark.parametrize("blocks,used", [([(10, True), (16, True), (7, False)], True),     # even blocks with their negatives + one-sided rows
                                          ([(9, True), (12, True)], False),                # an odd block: negatives do not pair up two by two
                                          ([(14, False)], True)])                           # no negatives at all: every pair is visited
