@@ -180,6 +180,15 @@ int mpcqp_factor(mpcqp_handle h, const mpcqp_factor_opts* opts, void* stream);
 /* x0 (batch, nx) -> U (batch, N*nu).  ADMM (+ polish). */
 int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U,
                 const mpcqp_info* info, const mpcqp_solve_opts* opts, void* stream);
+/* rho update of the ADMM stage (BASELINE.json north_star, subsystem 2: "rho updates"; the reference has no counterpart -- cvxopt's
+ * interior point has no penalty parameter).  One (Hs + rho I)^-1 serves the whole batch, so rho changes where the factorisation
+ * does: between solves.  After a solve that ran ADMM iterations (max_iter > 0) this call forms OSQP's ratio from the
+ * batch's final residuals -- rho_new = rho sqrt(r_prim / r_dual), geometric mean over the instances with both residuals
+ * non-zero -- and, when rho_new is more than `threshold` (> 1; <= 0: OSQP's 5) away from rho either way, factors again with
+ * it (synchronous, like a set-up mpcqp_factor) and rescales the kept scaled duals w = y / rho, so that a warm start stays
+ * valid.  *rho_out = the penalty in force afterwards, *refactored = 1 if it changed.  MPCQP_ESTATE without such a solve;
+ * shared models with box bounds only (the ADMM kernel's regime). */
+int mpcqp_adapt_rho(mpcqp_handle h, double threshold, double* rho_out, int* refactored, void* stream);
 /* receding horizon: shift the kept (z, w) one stage forward, repeating the last stage */
 int mpcqp_shift(mpcqp_handle h, void* stream);
 

@@ -54,6 +54,7 @@ SYMBOLS = [
     ("mpcqp_set_general_opts", C.c_int, [C.c_void_p, C.c_int, C.c_long]),
     ("mpcqp_general_rows", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     ("mpcqp_set_split", C.c_int, [C.c_void_p, C.c_int, C.c_double]),
+    ("mpcqp_adapt_rho", C.c_int, [C.c_void_p, C.c_double, C.POINTER(C.c_double), C.POINTER(C.c_int), C.c_void_p]),
     ("mpcqp_pin", C.c_int, [C.c_void_p, C.c_int]),
     ("mpcqp_split_info", C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_int]),
     ("mpcqp_assemble", C.c_int, [C.c_void_p, C.c_void_p]),

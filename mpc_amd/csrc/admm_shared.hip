@@ -30,6 +30,7 @@ struct AdmmParams {
     int* conv;              // [B] 1 if the eps criterion was met
     double* prim;           // [B]
     double* dual;           // [B]
+    double *pnorm, *dnorm;  // [B]: max(|x|, |z|) and rho |w| at the last check -- what the residuals are measured against
     int B, nx, SX, dev;
     int k_in_lds;           // 1: Kbfrag, Kufrag are staged behind M in LDS
     int max_iter, min_iter, check_every, warm, stop_on_stable;
@@ -255,7 +256,7 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
     }
 
     int it = 0;
-    double rp = 0.0, rd = 0.0;
+    double rp = 0.0, rd = 0.0, pnv = 1.0, dnv = 1.0;
     unsigned mask_prev = 0;
     bool have_prev = false, conv_last = false;
     int next_check = p.min_iter > 0 ? p.min_iter : 1;
@@ -291,6 +292,7 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
             }
             rp = st.rp;
             rd = rho * st.rd;
+            pnv = fmax(st.x, st.z); dnv = rho * st.w;
             const bool conv = (rp <= p.eps_abs + p.eps_rel * fmax(st.x, st.z)) &&
                               (rd <= p.eps_abs + p.eps_rel * rho * st.w);
             // active-set pattern unchanged since the previous check: good enough for the polish
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(256, 1) void admm_shared_box_kernel(AdmmParams p) {
         p.conv[inst] = conv_last ? 1 : 0;
         p.prim[inst] = rp;
         p.dual[inst] = rd;
+        p.pnorm[inst] = pnv; p.dnorm[inst] = dnv;
     }
 }
 
@@ -357,7 +360,7 @@ int launch_admm_shared_box(mpcqp_handle h, const double* x0, int B, const mpcqp_
     AdmmParams p;
     p.Mfrag = h->Mfrag; p.Kbfrag = h->Kbfrag; p.Kufrag = h->Kufrag;
     p.lbs = h->lbs; p.ubs = h->ubs; p.x0 = x0;
-    p.b0ws = h->b0ws; p.z = h->z; p.w = h->w; p.iters = h->it_ws; p.conv = h->it_ws + 2 * (size_t)h->Bcap; p.prim = h->rp_ws; p.dual = h->rd_ws;
+    p.b0ws = h->b0ws; p.z = h->z; p.w = h->w; p.iters = h->it_ws; p.conv = h->it_ws + 2 * (size_t)h->Bcap; p.prim = h->rp_ws; p.dual = h->rd_ws; p.pnorm = h->rd_ws + h->Bcap; p.dnorm = h->rd_ws + 2 * (size_t)h->Bcap;
     p.B = B; p.nx = h->dims.nx; p.SX = h->SX; p.dev = h->dev;
     p.max_iter = o.max_iter; p.min_iter = o.min_iter; p.check_every = o.check_every > 0 ? o.check_every : 1;
     p.warm = (o.warm_start && h->has_state) ? 1 : 0;

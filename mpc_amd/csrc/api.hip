@@ -1,5 +1,7 @@
 // extern "C" surface of libmpcqp.so (declared in include/mpcqp.h).
 #include "common.h"
+#include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <new>
 
@@ -41,7 +43,7 @@ int ensure_batch(mpcqp_handle h, int B) {
     TRY(dev_alloc(h, &h->b0ws, (size_t)need * h->NP));
     TRY(dev_alloc(h, &h->it_ws, (size_t)need * (5 + 32) + 96 + 1024));   // iters | need_big | converged | queue 1 | queue 2 | counters | bucket sizes (32 x 32) | the 32 buckets of the cold-start order
     TRY(dev_alloc(h, &h->rp_ws, (size_t)need));
-    TRY(dev_alloc(h, &h->rd_ws, (size_t)need));
+    TRY(dev_alloc(h, &h->rd_ws, (size_t)need * 3));      // dual residuals | what the two residuals are measured against (mpcqp_adapt_rho)
     // the hand-over records of the whole-instance cascade (2.6 KB per instance) are allocated by the first solve that takes
     // that cascade (ensure_handover): models solved component by component, one model per instance, warm-started and
     // ADMM-first solves never touch them
@@ -97,6 +99,29 @@ __global__ void unblock_kernel(const double* zb, double* out, int B, int NP, int
     if (idx >= (size_t)B * n) return;
     const int inst = (int)(idx / n), j = (int)(idx % n);
     out[idx] = zb[(size_t)inst * NP + j];
+}
+
+// sum over the batch of log(r_prim) - log(r_dual) (instances with both residuals > 0) and their number: one workgroup
+__global__ __launch_bounds__(256) void rho_stats_kernel(const double* rp, const double* rd, const double* pn, const double* dn, int B, double* out) {
+    __shared__ double ssum[256];
+    __shared__ int scnt[256];
+    double a = 0.0; int c = 0;
+    for (int i = threadIdx.x; i < B; i += 256) {
+        // OSQP's normalised residuals: r_prim / max(|x|, |z|), r_dual / (rho |w|), the scales the kernel's own stopping test uses
+        const double p = rp[i] / pn[i], d = rd[i] / dn[i];
+        if (p > 0.0 && d > 0.0 && isfinite(p) && isfinite(d)) { a += log(p) - log(d); ++c; }
+    }
+    ssum[threadIdx.x] = a; scnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) { ssum[threadIdx.x] += ssum[threadIdx.x + s]; scnt[threadIdx.x] += scnt[threadIdx.x + s]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { out[0] = ssum[0]; out[1] = (double)scnt[0]; }
+}
+
+__global__ __launch_bounds__(256) void scale_vec_kernel(double* v, size_t count, double f) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) v[i] *= f;
 }
 
 }  // namespace
@@ -155,7 +180,7 @@ int mpcqp_destroy(mpcqp_handle h) {
     (void)hipSetDevice(h->dev);
     void* ptrs[] = {h->Gam, h->QG, h->Phi, h->H, h->F, h->f0, h->d, h->Hs, h->M, h->Hi, h->W1, h->W2, h->Fs1,
                     h->Ku1, h->Cq, h->FsT, h->KuT, h->Mfrag, h->Kbfrag, h->Kufrag, h->lbs, h->ubs, h->rho_dev, h->flag_dev, h->mflag,
-                    h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws, h->hbuf1, h->hbuf2, h->facL, h->facBlk};
+                    h->z, h->w, h->b0ws, h->it_ws, h->rp_ws, h->rd_ws, h->hbuf1, h->hbuf2, h->facL, h->facBlk, h->adapt_ws};
     for (void* p : ptrs) if (p) (void)hipFree(p);
     general_free(h);
     split_free(h);
@@ -272,9 +297,44 @@ int mpcqp_solve(mpcqp_handle h, const double* x0, int batch, double* U, const mp
     // max_iter = 0 with the polish on: nothing for the ADMM kernel to do -- the active-set kernels start cold (empty set), or
     // from the kept (z, w) state when warm_start is set
     const bool skip_admm = o.max_iter == 0 && o.polish && (o.stages & 2);   // polish.hip: no_admm
-    if ((o.stages & 1) && h->dims.n_models == 1 && !skip_admm) TRY(launch_admm_shared_box(h, x0, batch, o, st));
+    h->admm_last = false;
+    if ((o.stages & 1) && h->dims.n_models == 1 && !skip_admm) { TRY(launch_admm_shared_box(h, x0, batch, o, st)); h->admm_last = true; }
     if (o.stages & 2) TRY(launch_polish_box(h, x0, batch, U, info, o, st));
     h->has_state = o.keep_state != 0; h->Blast = batch;
+    return MPCQP_OK;
+}
+
+int mpcqp_adapt_rho(mpcqp_handle h, double threshold, double* rho_out, int* refactored, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (refactored) *refactored = 0;
+    if (h->dims.n_models != 1 || h->general) { h->err = "adapt_rho: shared models with box bounds only (the ADMM kernel's regime)"; return MPCQP_ENOTIMPL; }
+    if (!h->factored || !h->admm_last || h->Blast < 1) { h->err = "adapt_rho: needs a solve that ran ADMM iterations (max_iter > 0) on the current factorisation"; return MPCQP_ESTATE; }
+    if (h->pinned) { h->err = "adapt_rho: a recorded graph points into this factorisation's buffers (mpcqp_pin): unpin first"; return MPCQP_ESTATE; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (!h->adapt_ws) HIPCHK(h, hipMalloc(reinterpret_cast<void**>(&h->adapt_ws), 2 * sizeof(double)));
+    hipLaunchKernelGGL(rho_stats_kernel, dim3(1), dim3(256), 0, st, h->rp_ws, h->rd_ws, h->rd_ws + h->Bcap, h->rd_ws + 2 * (size_t)h->Bcap, h->Blast, h->adapt_ws);
+    HIPCHK(h, hipGetLastError());
+    double sums[2] = {0.0, 0.0};
+    HIPCHK(h, hipMemcpyAsync(sums, h->adapt_ws, sizeof(sums), hipMemcpyDeviceToHost, st));
+    HIPCHK(h, hipStreamSynchronize(st));
+    const double thr = threshold > 1.0 ? threshold : 5.0;
+    double rho_new = h->rho;
+    if (sums[1] >= 1.0) rho_new = h->rho * std::exp(0.5 * sums[0] / sums[1]);      // rho sqrt(r_prim / r_dual), geometric mean
+    rho_new = std::min(std::max(rho_new, h->rho * 1e-3), h->rho * 1e3);             // one update never moves it further than that
+    if (!(rho_new > h->rho * thr) && !(rho_new < h->rho / thr)) { if (rho_out) *rho_out = h->rho; return MPCQP_OK; }
+    const double rho_old = h->rho;
+    const bool had_state = h->has_state;
+    mpcqp_factor_opts fo{rho_new, 0, 1};
+    TRY(mpcqp_factor(h, &fo, stream));
+    h->admm_last = false;               // the residuals on record belong to the old penalty
+    if (had_state && h->w && h->Blast > 0) {
+        const size_t count = (size_t)h->Blast * h->NP;
+        hipLaunchKernelGGL(scale_vec_kernel, dim3((unsigned)std::min<size_t>((count + 255) / 256, 4096)), dim3(256), 0, st, h->w, count, rho_old / h->rho);
+        HIPCHK(h, hipGetLastError());
+    }
+    if (rho_out) *rho_out = h->rho;
+    if (refactored) *refactored = 1;
     return MPCQP_OK;
 }
 

@@ -81,6 +81,8 @@ struct mpcqp_handle_s {
     int* sp_iws = nullptr; double* sp_part = nullptr;           // int / double workspace of the split solve (split.hip)
     double *sp_hb1 = nullptr, *sp_hb2 = nullptr; int sp_cap1 = 0, sp_cap2 = 0;   // hand-over records 8 -> 16 and 16 -> 32 slots
     bool assembled = false, factored = false, has_state = false;
+    bool admm_last = false;                      // the last solve ran ADMM iterations (their residuals are in rp_ws / rd_ws): mpcqp_adapt_rho
+    double* adapt_ws = nullptr;                  // [2]: sum of log(r_prim / r_dual), number of instances in it (mpcqp_adapt_rho)
     int pinned = 0;                              // > 0: a recorded graph holds this handle's device pointers (mpcqp_pin): nothing may be freed or re-grown
     std::string err;
 };

@@ -429,6 +429,16 @@ class Planner:
         ci = _lib.Info(*[_ptr(getattr(info, f[0])) for f in _lib.Info._fields_])
         return U, info, ci
 
+    def adapt_rho(self, threshold=0.0):
+        """rho update of the ADMM stage (mpcqp_adapt_rho): after a solve that ran ADMM iterations, move the penalty by OSQP's
+        ratio sqrt(r_prim / r_dual) of the batch's final residuals and factor again if that is more than `threshold`
+        (default 5) away from the current one.  Returns (rho in force, whether it changed)."""
+        rho, changed = C.c_double(0.0), C.c_int(0)
+        self._check(self._lib.mpcqp_adapt_rho(self._h, float(threshold), C.byref(rho), C.byref(changed), self._stream()))
+        if changed.value:
+            self.rho = rho.value
+        return rho.value, bool(changed.value)
+
     def shift(self, recenter=False):
         """Receding horizon: move the kept primal/dual state one stage forward (last stage repeated); recenter=True also
         zeroes the primal state in the same launch (shift().recenter() of a re-linearising loop)."""

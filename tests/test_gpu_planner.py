@@ -586,3 +586,45 @@ def test_a_recorded_solve_replays_bit_for_bit(cfg, batch, split):
     pl.set_cost(prob["Q"], prob["R"], prob["P"]).setup()
     # (another batch size may take other kernels: the same point to rounding, not to the bit)
     assert float((pl.solve(big)[:batch] - Ua).abs().max()) <= 1e-11 * float(Ua.abs().max())
+
+
+def test_rho_update_recovers_from_a_bad_penalty():
+    """mpcqp_adapt_rho (BASELINE.json north_star, subsystem 2: "rho updates").  The ADMM stage alone (no active-set stage), started
+    with a penalty a hundred times too small, runs into its iteration cap far from the answer; one update from the batch's
+    final residuals (OSQP's ratio of the normalised residuals) brings rho back to the neighbourhood of the spectral choice and
+    the same solve converges.  At the spectral choice itself the update leaves rho alone.  The kept scaled duals are
+    rescaled with rho, so a warm start after the update confirms the solution.  (The reference has no counterpart: cvxopt's
+    interior point has no penalty parameter; the answers are checked against the default solve, which meets the oracle bar.)"""
+    import torch
+    from mpc_amd.configs import make_config
+    from mpc_amd.planner import Planner
+    prob = make_config(3, batch=256, seed=1)
+    pl = Planner(prob["nx"], prob["nu"], prob["N"]).set_model(prob["A"], prob["B"]).set_cost(prob["Q"], prob["R"], prob["P"])
+    pl.set_constraints(prob["u_min"], prob["u_max"])
+    x0 = torch.as_tensor(prob["x0"], device="cuda:0")
+    Uref = pl.solve(x0).clone()                                     # default: active-set kernels, oracle-accurate
+    rho0 = pl.rho
+    with pytest.raises(RuntimeError):
+        pl.adapt_rho()                                              # no ADMM iterations on record
+    err = lambda U: float((U - Uref).abs().max() / Uref.abs().max())
+    # at the spectral choice: nothing to do
+    pl.solve(x0, max_iter=2000, polish=False)
+    it_default = float(pl.info.iters.float().mean())
+    rho, changed = pl.adapt_rho()
+    assert not changed and rho == rho0
+    # a hundred times too small
+    pl.setup(rho=rho0 * 0.01)
+    U = pl.solve(x0, max_iter=2000, polish=False).clone()
+    assert int(pl.info.iters.min()) == 2000 and err(U) > 1e-2       # stuck at the cap, far away
+    rho, changed = pl.adapt_rho()
+    assert changed and 0.2 * rho0 <= rho <= 5.0 * rho0 and pl.rho == rho
+    U = pl.solve(x0, max_iter=2000, polish=False).clone()
+    assert float(pl.info.iters.float().mean()) <= 1.5 * it_default and err(U) <= 1e-3
+    # a hundred times too large: the update moves it down by more than the threshold
+    pl.setup(rho=rho0 * 100.0)
+    pl.solve(x0, max_iter=2000, polish=False, keep_state=True)
+    rho, changed = pl.adapt_rho()
+    assert changed and rho < rho0 * 100.0 / 5.0
+    # the state kept across the update (w = y / rho rescaled): a warm start with the active-set stage lands on the answer
+    Uw = pl.solve(x0, warm_start=True, max_iter=20, polish=True)
+    assert bool((pl.info.status == 0).all()) and err(Uw) <= 1e-8
