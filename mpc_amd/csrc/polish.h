@@ -50,6 +50,8 @@ struct PolParams {
     const double* sp_img;          // all of it (Hi | lbs | ubs | d | bounds -+ tolerance | perm | KuT) laid out as the kernels' LDS for rows of sp_ld
     double* sp_part; int* sp_steps;                // per sub-instance: its part of the objective, its steps
     int seg_lo, seg_hi;            // split: the buckets (keys) a launch over the cold-start order takes
+    int *redo_q, *redo_count;      // split, LAST pass of the cascade: the instance of a component it could not finish is appended here
+                                   // (once per failing component; split_tail_kernel skips the repeats) -- solved again as a whole
 };
 
 // fast path; returns MPCQP_ENOTIMPL if the shape does not fit it (the caller then uses the wave kernel)

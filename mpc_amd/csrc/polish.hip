@@ -579,17 +579,37 @@ int launch_pol(const PolParams& p, hipStream_t st, int blocks = 0) {
 
 }  // namespace
 
-// After the passes of a component-split solve (split.hip): one lane per instance adds up its components' parts of the objective
-// and their step counts, in component order, and writes the instance's record; an instance with a component the split
-// cascade could not finish (need != 0: more active rows than the last pass holds, or a numerical guard) is queued and
-// solved again as a whole, from the empty set, by the any-size kernel -- p is the UNSPLIT parameter set plus sp_C / sp_part /
-// sp_steps.
-__global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const int* need, const double* c0, int* redo, int* redo_count,
-                                                           int* zero, int nzero) {
-    // the counters of the solve that ends here, ready for the next one (no memset in front of every solve): all but the
-    // redo queue's, which the kernel after this one reads -- split_key_kernel clears that one
-    if (blockIdx.x == 0) for (int i = threadIdx.x; i < nzero; i += 256) if (zero + i != redo_count) zero[i] = 0;
-    const int inst = blockIdx.x * 256 + threadIdx.x, C = p.sp_C;
+// After the passes of a component-split solve (split.hip), ONE launch of one-wave workgroups with two kinds of work:
+//   * workgroups [0, redo_blocks): the instances the last pass of the cascade queued (a component with more active rows than
+//     that pass holds, or a numerical guard) are solved again as a whole, from the empty set, by the any-size method
+//     (polish_wave, one wave per instance; an instance queued by several of its components is taken once);
+//   * the others, 64 instances each: one lane per instance adds up its components' parts of the objective and their step
+//     counts, in component order, and writes the instance's record -- unless a component is unfinished (need != 0): that
+//     instance's record is the redo's.  The first of them also zeroes the counters for the next solve (no memset in front of
+//     every solve): all but the redo queue's, which the other kind reads -- split_key_kernel clears that one.
+// The two do not depend on each other (the queue was written by the launch before), so they share a launch: the redo is
+// nearly always empty, and as a launch of its own it cost a small batch 4 us of its 74.
+// p is the UNSPLIT parameter set plus sp_C / sp_part / sp_steps, qin / qin_count = the redo queue.
+__global__ __launch_bounds__(64) void split_tail_kernel(PolParams p, const int* need, const double* c0, int* zero, int nzero,
+                                                        int redo_blocks) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    if ((int)blockIdx.x < redo_blocks) {
+        WaveLds<128>& s = reinterpret_cast<WaveLds<128>*>(smem)[0];
+        const int cnt = *p.qin_count;
+        for (int qi = blockIdx.x; qi < cnt; qi += redo_blocks) {
+            const int inst = p.qin[qi];
+            bool seen = false;                          // queued before by another of its components?
+            for (int j = lane; j < qi; j += 64) seen = seen || p.qin[j] == inst;
+            if (__any(seen)) continue;
+            polish_wave<128>(p, inst, s, lane);
+            wave_sync();
+        }
+        return;
+    }
+    const int fb = blockIdx.x - redo_blocks;
+    if (fb == 0) for (int i = lane; i < nzero; i += 64) if (zero + i != p.qin_count) zero[i] = 0;
+    const int inst = fb * 64 + lane, C = p.sp_C;
     if (inst >= p.B) return;
     constexpr int CM = 8;
     double pv[CM]; int nv[CM], sv[CM];
@@ -604,7 +624,7 @@ __global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const in
     bool ok = true; int steps = 0;
 #pragma unroll
     for (int c = 0; c < CM; ++c) { ok = ok && nv[c] == 0; o += pv[c]; steps += sv[c]; }
-    if (!ok) { redo[atomicAdd(redo_count, 1)] = inst; return; }
+    if (!ok) return;            // in the redo queue (the last pass put it there)
     if (p.info.status) p.info.status[inst] = MPCQP_SOLVED;
     if (p.info.obj) p.info.obj[inst] = o;
     if (p.info.iters) p.info.iters[inst] = 0;
@@ -615,12 +635,14 @@ __global__ __launch_bounds__(256) void split_finish_kernel(PolParams p, const in
 
 int launch_split_finish(const PolParams& pin, const int* need, const double* c0, int* redo, int* redo_count, int* zero, int nzero,
                         hipStream_t st) {
-    hipLaunchKernelGGL(split_finish_kernel, dim3(ceil_div(pin.B, 256)), dim3(256), 0, st, pin, need, c0, redo, redo_count, zero, nzero);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
     PolParams p = pin;
     p.qin = redo; p.qin_count = redo_count;
-    return launch_pol<128, 1>(p, st, 64);       // a short grid: the queue is empty unless a component hit a numerical guard
+    constexpr int REDO_BLOCKS = 64;     // a short grid: the queue is empty unless a component outgrew the cascade or hit a numerical guard
+    const size_t lds = sizeof(WaveLds<128>);
+    hipError_t e = ensure_dyn_lds(p.dev, reinterpret_cast<const void*>(&split_tail_kernel), lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(split_tail_kernel, dim3(REDO_BLOCKS + ceil_div(pin.B, 64)), dim3(64), lds, st, p, need, c0, zero, nzero, REDO_BLOCKS);
+    return (int)hipGetLastError();
 }
 
 int launch_polish_box(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info,

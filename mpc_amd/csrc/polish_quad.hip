@@ -749,6 +749,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
     int qslot = -1;
     if (valid && g == 0) {
         if (!okk && p.qout) { qslot = atomicAdd(p.qout_count, 1); p.qout[qslot] = sub; }      // queue for the next, larger pass
+        else if (SPLIT && !okk && p.redo_q) p.redo_q[atomicAdd(p.redo_count, 1)] = inst;     // no pass left: the instance as a whole
         const bool give = over && why == 3 && qslot >= 0 && ((p.hand_out && qslot < p.hand_out_cap) || p.hand_zw);
         p.need_big[sub] = okk ? 0 : (why == 3 && !give ? 9 : (why ? why : 7));       // 3 = handed over, 9 = list full, start again
     }

@@ -220,7 +220,7 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     p.Hi = h->sp_Hi; p.KuT = h->sp_KuT; p.lbs = h->sp_lbs; p.ubs = h->sp_ubs; p.d = h->sp_d;
     p.n = h->sp_ns; p.B = Binst * C;
     p.need_big = w.need;
-    p.seg = nullptr; p.seg_counts = nullptr; p.q_gate = 0; p.hand_zw = 0;
+    p.seg = nullptr; p.seg_counts = nullptr; p.q_gate = 0; p.hand_zw = 0; p.redo_q = nullptr; p.redo_count = nullptr;
     // x_unc for everyone: components it solves are finished there, the rest ordered by the number of rows it violates
     {
         PolParams k = pin;
@@ -259,16 +259,17 @@ int launch_polish_split(mpcqp_handle h, const PolParams& pin, hipStream_t st, in
     PolParams c = p;
     c.qin = w.q2; c.qin_count = w.counters + 1; c.qout = nullptr; c.qout_count = nullptr;
     c.hand_in = h->sp_hb2; c.hand_out = nullptr; c.hand_out_cap = 0;
+    c.redo_q = w.q1; c.redo_count = w.counters + REDO;        // queue 1 is free again: what this pass cannot finish is solved again as a whole
     rc = launch_oct_split(c, 32, st);
     if (rc != 0) return leave(rc);
     // the instances' records from their components' parts; an instance with a component the cascade could not finish (more than
-    // 32 active rows in a component of more than 32 rows, or a numerical guard) is solved again as a whole, unsplit, from the
-    // empty set, by the any-size kernel
+    // 32 active rows in a component of more than 32 rows, or a numerical guard: the last pass queued it) is solved again as a
+    // whole, unsplit, from the empty set, by the any-size method -- both in one launch (split_tail_kernel)
     PolParams f = pin;
     f.pass = 1; f.qin = nullptr; f.qin_count = nullptr; f.qout = nullptr; f.qout_count = nullptr;
     f.hand_in = nullptr; f.hand_out = nullptr; f.hand_zw = 0; f.seg = nullptr;
     f.sp_C = C; f.sp_part = h->sp_part; f.sp_steps = w.steps;
-    rc = launch_split_finish(f, w.need, c0, w.q1, w.counters + REDO, w.counters, NCNT, st);      // queue 1 is free again
+    rc = launch_split_finish(f, w.need, c0, w.q1, w.counters + REDO, w.counters, NCNT, st);
     if (rc != 0) return leave(rc);
     return 0;
 }
