@@ -5,7 +5,7 @@ Default = the headline metric (BASELINE.json): QP solves/sec at batch 65,536, nx
 configs[2] = "config 3" in SURVEY.md's 1-based numbering), fp64, synthetic x0 (numpy default_rng(0)).  One "step" = one
 pass of the hot path over the batch: mpcqp_solve (cold-start ordering kernels + dual active-set kernels) with x0 already
 resident in HBM; the model set-up (assemble + factor) is outside the timed region because the model is shared and fixed
-(LTI) -- it is reported as `setup_ms`.
+(LTI) -- it is reported as `setup_ms` (first call, with the one-off costs) and `setup_warm_ms` (again on the warm handle).
 
     python bench.py --gpus N --steps K --warmup W [--config 2|3|4|5] [--scaling strong|weak]
 
@@ -363,6 +363,17 @@ class BoxWorkload:
         pl.setup(rho=args.rho)
         torch.cuda.synchronize(dev)
         self.setup_ms = (time.perf_counter() - t0) * 1e3
+        # the same set-up again on the warm handle (code objects loaded, workspaces allocated): what a caller who changes the
+        # weights between batches pays per change; the first call above also carries the one-off costs
+        ts = []
+        for _ in range(3):
+            pl.set_cost(prob["Q"], prob["R"], prob["P"])
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            pl.setup(rho=args.rho)
+            torch.cuda.synchronize(dev)
+            ts.append((time.perf_counter() - t0) * 1e3)
+        self.setup_warm_ms = min(ts)
         self.x0_all = torch.as_tensor(prob["x0"], device=dev)
         self.x0 = self.x0_all[lo:hi].contiguous()
         self.opts = {} if args.max_iter is None else {"max_iter": args.max_iter}
@@ -548,7 +559,7 @@ class BoxWorkload:
                   ("with_state_ms" if not args.keep_state else "without_state_ms"): other_ms,
                   "admm_iters_mean": iters_mean, "admm_iters_max": iters_max,
                   "polish_steps_mean": psteps_mean, "polish_steps_max": psteps_max,
-                  "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": self.setup_ms,
+                  "solved_fraction": n_solved / B, "rho": pl.rho, "setup_ms": self.setup_ms, "setup_warm_ms": self.setup_warm_ms,
                   "p50_batch_latency_ms": p50_ms, "p99_batch_latency_ms": p99_ms, "mean_batch_latency_ms": both_ms,
                   "admm_kernel_ms": admm_ms, "polish_kernels_ms": max(both_ms - admm_ms, 0.0),
                   "first_pass_ms": pass_a_ms, "cold_order_ms": order_ms,
