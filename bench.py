@@ -612,8 +612,7 @@ class LtvWorkload:
     def step(self):
         cfg = self.cfg
         self.torch.add(self.x[:, :1], self.ahead, out=self.x_ref[:, :, 0])             # one launch: x + v_ref dt k into the strided column
-        u0 = self.loop.step(self.x, self.x_ref, warm=True)
-        self.x = self.loop.model.step(self.x, u0)
+        _, self.x = self.loop.step(self.x, self.x_ref, warm=True, advance=True)    # the plant's step rides in the apply launch
         self.nsteps += 1
         if self.ranks.dist is not None:
             self.ranks.flag_allreduce(self.loop.pl.info.status)

@@ -334,6 +334,10 @@ int mpcqp_ltv_bicycle(int device_id, int batch, int N, double dt, double L, cons
  * bicycle itself one step on under u0.  One launch for the apply / shift of a receding-horizon step. */
 int mpcqp_ltv_bicycle_apply(int device_id, int batch, int N, double dt, double L, const double* plan_in, const double* dU,
                             double* plan_out, double* u0, const double* x, double* x_next, void* stream);
+/* mpcqp_ltv_bicycle_apply for the batch of the handle's last solve AND mpcqp_shift_recenter of its kept state, as one launch:
+ * everything a re-linearising closed loop does between two solves (same arguments; batch and N are the handle's) */
+int mpcqp_ltv_bicycle_advance(mpcqp_handle h, double dt, double L, const double* plan_in, const double* dU, double* plan_out,
+                              double* u0, const double* x, double* x_next, void* stream);
 /* x_next = f(x, u): the plant of the closed loop (x, x_next (batch, 4); u (batch, 2)) */
 int mpcqp_ltv_bicycle_step(int device_id, int batch, double dt, double L, const double* x, const double* u, double* x_next,
                            void* stream);

@@ -72,6 +72,7 @@ SYMBOLS = [
     ("mpcqp_ltv_bicycle_apply", C.c_int, [C.c_int, C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 7),
     ("mpcqp_ltv_bicycle_step", C.c_int, [C.c_int, C.c_int, C.c_double, C.c_double] + [C.c_void_p] * 4),
     ("mpcqp_solve_dense_strided", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_long] * 6 + [C.c_void_p] * 8 + [C.c_void_p]),
+    ("mpcqp_ltv_bicycle_advance", C.c_int, [C.c_void_p, C.c_double, C.c_double] + [C.c_void_p] * 7),
     ("mpcqp_default_dense_opts", None, [C.POINTER(DenseOpts)]),
     ("mpcqp_solve_dense_opts", C.c_int, [C.c_int] * 5 + [C.c_void_p, C.c_long] * 6 + [C.c_void_p] * 8 +
      [C.POINTER(DenseOpts), C.c_void_p]),

@@ -388,6 +388,20 @@ int mpcqp_shift_recenter(mpcqp_handle h, void* stream) {
     return MPCQP_OK;
 }
 
+int mpcqp_ltv_bicycle_advance(mpcqp_handle h, double dt, double L, const double* plan_in, const double* dU, double* plan_out,
+                              double* u0, const double* x, double* x_next, void* stream) {
+    if (!h) return MPCQP_EINVAL;
+    if (h->dims.nu != 2 || h->dims.nx != 4) { h->err = "ltv_bicycle_advance: the handle is not a bicycle's (nx 4, nu 2)"; return MPCQP_EINVAL; }
+    if (!plan_in || !dU || !plan_out || !u0 || plan_in == plan_out || (!x) != (!x_next) || !(dt > 0.0) || !(L > 0.0)) {
+        h->err = "ltv_bicycle_advance: plan_in, dU, plan_out (not aliasing plan_in), u0 are required; x and x_next both or neither"; return MPCQP_EINVAL;
+    }
+    if (!h->has_state) { h->err = "shift: no solution state yet"; return MPCQP_ESTATE; }
+    HIPCHK(h, hipSetDevice(h->dev));
+    if (launch_bicycle_advance(h->Blast, h->dims.N, dt, L, plan_in, dU, plan_out, u0, x, x_next, h->z, h->w, h->NP, h->n, h->dims.nu,
+                               static_cast<hipStream_t>(stream)) != MPCQP_OK) { h->err = "ltv_bicycle_advance: launch failed"; return MPCQP_EHIP; }
+    return MPCQP_OK;
+}
+
 int mpcqp_recenter(mpcqp_handle h, void* stream) {
     if (!h) return MPCQP_EINVAL;
     if (!h->has_state) { h->err = "recenter: no solution state yet"; return MPCQP_ESTATE; }

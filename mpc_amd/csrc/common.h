@@ -120,3 +120,6 @@ int split_setup(mpcqp_handle h, hipStream_t st);
 void split_free(mpcqp_handle h);
 int solve_general(mpcqp_handle h, const double* x0, int B, double* U, const mpcqp_info* info, hipStream_t st, int warm);
 void general_free(mpcqp_handle h);
+// ltv_models.hip: apply + plant + shift / re-centre of (z, w) in one launch
+int launch_bicycle_advance(int B, int N, double dt, double L, const double* plan_in, const double* dU, double* plan_out, double* u0,
+                           const double* x, double* x_next, double* z, double* w, int NP, int n, int nu, hipStream_t st);

@@ -6,6 +6,7 @@
 // Jacobian blocks of CollocationBasedPlanner2D.py:88-347, SE3Planner.py:136-177); the reference has no bicycle, the
 // model is the one SURVEY.md section 8(d) fixes for config 4.
 #include "common.h"
+#include <algorithm>
 
 namespace {
 
@@ -149,6 +150,48 @@ __global__ __launch_bounds__(256) void bicycle_apply_kernel(int B, int N, double
     }
 }
 
+// bicycle_apply_kernel and the shift + re-centring of the handle's kept (z, w) (api.hip: shift_kernel with zero_z) as ONE
+// launch: what a re-linearising closed loop does between two solves (mpcqp_ltv_bicycle_advance).  Block b: the shift of
+// instances 4 b .. 4 b + 3 (one wave each), then elements 256 b .. of the plan.
+__global__ __launch_bounds__(256) void bicycle_advance_kernel(int B, int N, double dt, double L, const double* __restrict__ plan_in,
+                                                              const double* __restrict__ dU, double* __restrict__ plan_out,
+                                                              double* __restrict__ u0, const double* __restrict__ x,
+                                                              double* __restrict__ x_next, double* __restrict__ z,
+                                                              double* __restrict__ w, int NP, int n, int nu) {
+    {
+        const int inst = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+        if (inst < B) {
+            double* zb = z + (size_t)inst * NP;
+            double* wb = w + (size_t)inst * NP;
+            double wv[2];
+            for (int q = 0; q < 2; ++q) {
+                const int r = lane + 64 * q;
+                const int src = (r + nu < n) ? r + nu : r;
+                wv[q] = r < n ? wb[src] : 0.0;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int q = 0; q < 2; ++q) {
+                const int r = lane + 64 * q;
+                if (r < n) { zb[r] = 0.0; wb[r] = wv[q]; }
+            }
+        }
+    }
+    const long e = (long)blockIdx.x * 256 + threadIdx.x;
+    if (e >= (long)B * N) return;
+    const int i = (int)(e / N), k = (int)(e - (long)i * N);
+    const int ks = k < N - 1 ? k + 1 : N - 1;
+    const size_t src = ((size_t)i * N + ks) * 2, dst = ((size_t)i * N + k) * 2;
+    plan_out[dst] = plan_in[src] + dU[src];
+    plan_out[dst + 1] = plan_in[src + 1] + dU[src + 1];
+    if (k == 0) {
+        const size_t f = (size_t)i * N * 2;
+        const double a = plan_in[f] + dU[f], delta = plan_in[f + 1] + dU[f + 1];
+        u0[2 * i] = a; u0[2 * i + 1] = delta;
+        if (x && x_next) bicycle_f(x + 4 * (size_t)i, a, delta, dt, L, x_next + 4 * (size_t)i);
+    }
+}
+
 __global__ __launch_bounds__(256) void bicycle_step_kernel(int B, double dt, double L, const double* __restrict__ x,
                                                            const double* __restrict__ u, double* __restrict__ x_next) {
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -187,6 +230,15 @@ extern "C" int mpcqp_ltv_bicycle_apply(int device_id, int batch, int N, double d
     if (hipSetDevice(device_id) != hipSuccess) return MPCQP_EHIP;
     hipLaunchKernelGGL(bicycle_apply_kernel, dim3((unsigned)(((long)batch * N + 255) / 256)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), batch, N, dt, L, plan_in, dU, plan_out, u0, x, x_next);
+    return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
+}
+
+// api.hip (mpcqp_ltv_bicycle_advance): the launch itself; the handle's state is checked there
+int launch_bicycle_advance(int B, int N, double dt, double L, const double* plan_in, const double* dU, double* plan_out, double* u0,
+                           const double* x, double* x_next, double* z, double* w, int NP, int n, int nu, hipStream_t st) {
+    const long blocks = std::max<long>(((long)B * N + 255) / 256, (B + 3) / 4);
+    hipLaunchKernelGGL(bicycle_advance_kernel, dim3((unsigned)blocks), dim3(256), 0, st, B, N, dt, L, plan_in, dU, plan_out, u0, x, x_next,
+                       z, w, NP, n, nu);
     return hipGetLastError() == hipSuccess ? MPCQP_OK : MPCQP_EHIP;
 }
 

@@ -143,8 +143,10 @@ class ClosedLoopLTV:
         ubar[:, :-1].copy_(plan[:, 1:]); ubar[:, -1].copy_(plan[:, -1])
         pl.shift(recenter=True)
 
-    def step(self, x, x_ref, warm=True, **opts):
-        """x (B,nx) current states, x_ref (B,N,nx) references for x_1..x_N.  Returns the applied input (B,nu)."""
+    def step(self, x, x_ref, warm=True, advance=False, **opts):
+        """x (B,nx) current states, x_ref (B,N,nx) references for x_1..x_N.  Returns the applied input (B,nu); with
+        ``advance=True`` (bicycle on the GPU) also the plant's next state under it, (u0, x_next) -- computed by the launch
+        that applies the solution (mpcqp_ltv_bicycle_apply with x / x_next) instead of one of its own."""
         Bn = x.shape[0]
         first = self.plan is None
         if first:
@@ -171,16 +173,23 @@ class ClosedLoopLTV:
                 self._plan2 = torch.empty_like(ubar)
             u0 = torch.empty((Bn, self.model.nu), dtype=torch.float64, device=self.device)
             p = lambda t: C.c_void_p(t.data_ptr())
-            rc = pl._lib.mpcqp_ltv_bicycle_apply(self.device.index or 0, Bn, self.N, self.model.dt, self.model.L, p(ubar),
-                                                 p(dU.contiguous()), p(self._plan2), p(u0), None, None, pl._stream())
-            if rc != 0:
-                raise RuntimeError(f"mpcqp_ltv_bicycle_apply failed with code {rc}")
+            x_next = None
+            if advance:
+                x = x.contiguous()
+                x_next = torch.empty_like(x)
+            # plan += dU, applied input, shifted plan, (the plant,) and the shift + re-centring of the kept state: one launch
+            pl._check(pl._lib.mpcqp_ltv_bicycle_advance(pl._h, self.model.dt, self.model.L, p(ubar), p(dU.contiguous()),
+                                                        p(self._plan2), p(u0), p(x) if advance else None,
+                                                        p(x_next) if advance else None, pl._stream()))
             self.plan, self._plan2 = self._plan2, ubar       # `last["ubar"]` stays valid until the step after next
+            pl.no_sync, pl.check_inputs = True, False
+            return (u0, x_next) if advance else u0
         else:
             plan = ubar + dU
             u0 = plan[:, 0].clone()
             self.plan = torch.cat((plan[:, 1:], plan[:, -1:]), dim=1).contiguous()
+            x_next = self.model.step(x, u0) if advance else None
         pl.shift(recenter=True)
         # after the first (synchronous, validated) step the set-up calls no longer wait for the device
         pl.no_sync, pl.check_inputs = True, False
-        return u0
+        return (u0, x_next) if advance else u0
