@@ -20,6 +20,7 @@
 //
 // Per solve: scale (q, h) -> GEMM xu = -Qs Hi -> GEMM res = Xu Cs' - cs -> one 1024-thread workgroup per instance.
 #include "common.h"
+#include <atomic>
 #include <algorithm>
 #include <cstdint>
 
@@ -1156,12 +1157,13 @@ static int rows_solve_impl(int device_id, int batch, int n, int m, const double*
     if (lds1 > 160 * 1024) return MPCQP_ENOTIMPL;
     // residuals in LDS: only when the launch is one round of one workgroup per CU either way (a larger batch wants the second
     // workgroup per CU more than the shorter sweep) and they fit behind the first pass's arrays
-    static int ncu_of[64] = {};         // CUs per device, asked once (0: not yet; a failed query leaves the residuals in memory)
-    if (device_id < 64 && ncu_of[device_id] == 0) {
+    static std::atomic<int> ncu_of[64];     // CUs per device, asked once (0: not yet; a failed query leaves the residuals in memory)
+    if (device_id < 64 && ncu_of[device_id].load(std::memory_order_relaxed) == 0) {
         int v = 0;
-        ncu_of[device_id] = (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ? v : -1;
+        ncu_of[device_id].store((hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && v > 0) ? v : -1,
+                                std::memory_order_relaxed);
     }
-    const int ncu = device_id < 64 ? ncu_of[device_id] : -1;
+    const int ncu = device_id < 64 ? ncu_of[device_id].load(std::memory_order_relaxed) : -1;
     const size_t lds1r = ((lds1 + 15) & ~(size_t)15) + (size_t)m * sizeof(double);
     r.res_lds = (batch <= ncu && lds1r <= 160 * 1024) ? 1 : 0;
     if (r.res_lds) lds1 = lds1r;
