@@ -1016,7 +1016,7 @@ __global__ __launch_bounds__(256) void rows_mirror_pairs_kernel(const int* mir, 
     if (q >= m / 2) return;
     const int a = mir[2 * q], b = mir[2 * q + 1];
     const bool none = a < 0 && b < 0;
-    const bool pair = a >= 0 && (a & 1) == 0 && b == a + 1 && mir[a] == 2 * q && mir[a + 1] == 2 * q + 1;
+    const bool pair = a >= 0 && (a & 1) == 0 && a + 1 < m && b == a + 1 && mir[a] == 2 * q && mir[a + 1] == 2 * q + 1;
     mir2[q] = pair ? a / 2 : -1;
     if (!none && !pair) atomicAnd(ok, 0);
 }
