@@ -901,13 +901,15 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
     int sub = valid ? (p.qin ? p.qin[slot0 + li] : slot0 + li) : 0;
     if (p.seg) {        // my place in the cold-start order (largest bucket first) -> bucket and offset, from the buckets' sizes
         const int pos = slot0 + li;
-        int bk = 0, off = 0, acc = 0;
+        int bk = 0, accb = 0, acc = 0;      // (as in oct_body_split: the last bucket, in this order, whose start the place has reached)
 #pragma unroll
         for (int k = NBIN - 1; k >= 0; --k) {
             const int c = p.seg_counts[k * BIN_STRIDE];
-            if (pos >= acc && pos < acc + c) { bk = k; off = pos - acc; }
+            const bool ge = pos >= acc;
+            bk = ge ? k : bk; accb = ge ? acc : accb;
             acc += c;
         }
+        const int off = pos - accb;
         sub = valid ? p.seg[(size_t)bk * p.B + off] : 0;
     }
     const int inst = sub, comp = 0;
@@ -1013,13 +1015,18 @@ __device__ __forceinline__ void oct_body_split(const PolParams& p) {
     const int slot = blockIdx.x * IPW + li;
     int sub = 0;
     if (!p.qin && p.seg) {      // my place in the cold-start order (largest bucket first) -> bucket and offset, from the buckets' sizes;
-        int bk = 0, off = 0, acc = 0;       // split_key_kernel queued only the components with something to do
+        // (the running sum `acc` is uniform -- scalar loads and adds; per lane one comparison and two selects per bucket: the
+        // place belongs to the LAST bucket, in this order, whose start it has reached -- an empty bucket starts where the next
+        // one does and loses to it)
+        int bk = 0, accb = 0, acc = 0;      // split_key_kernel queued only the components with something to do
 #pragma unroll
         for (int k = NBIN - 1; k >= 0; --k) {        // only the buckets this launch is given (the others run beside it)
             const int c = (k >= p.seg_lo && k <= p.seg_hi) ? p.seg_counts[k * BIN_STRIDE] : 0;
-            if (slot >= acc && slot < acc + c) { bk = k; off = slot - acc; }
+            const bool ge = slot >= acc;
+            bk = ge ? k : bk; accb = ge ? acc : accb;
             acc += c;
         }
+        const int off = slot - accb;
         total = acc;
         if ((int)blockIdx.x * IPW >= total) return;
         sub = slot < total ? p.seg[(size_t)bk * p.B + off] : 0;
