@@ -117,6 +117,37 @@ __device__ __forceinline__ void grp_max(double& v, int& code) {
 
 constexpr int BIGI = 1 << 20;
 
+// Reductions that carry an index in the value.  A positive double orders like its bit pattern, so with the low KEYBITS bits
+// of the mantissa replaced by an index the maximum (minimum) of the KEYS is the value AND its owner in one v_max_f64
+// (v_min_f64) per step of the butterfly -- no comparison chain, no second register riding along.  The key differs from the
+// value by < 2^-42 of it: far inside what "most violated row" or "first blocking multiplier" mean, and the quantities that
+// are derived from it (a step length) are restored to full accuracy by the refinement every solve ends with.
+constexpr int KEYBITS = 10;
+__device__ __forceinline__ double key_pack(double v, int idx) {
+    return __hiloint2double(__double2hiint(v), (__double2loint(v) & ~((1 << KEYBITS) - 1)) | idx);
+}
+__device__ __forceinline__ int key_index(double k) { return __double2loint(k) & ((1 << KEYBITS) - 1); }
+template <int G>
+__device__ __forceinline__ double grp_fmax(double v) {
+    v = fmax(v, dpp_d<DPP_XOR1>(v));
+    v = fmax(v, dpp_d<DPP_XOR2>(v));
+    if (G >= 8) v = fmax(v, dpp_d<DPP_HMIRROR>(v));
+    if (G >= 16) v = fmax(v, dpp_d<DPP_ROR8>(v));
+    if (G >= 32) v = fmax(v, __shfl_xor(v, 16));
+    if (G == 64) v = fmax(v, __shfl_xor(v, 32));
+    return v;
+}
+template <int G>
+__device__ __forceinline__ double grp_fmin(double v) {
+    v = fmin(v, dpp_d<DPP_XOR1>(v));
+    v = fmin(v, dpp_d<DPP_XOR2>(v));
+    if (G >= 8) v = fmin(v, dpp_d<DPP_HMIRROR>(v));
+    if (G >= 16) v = fmin(v, dpp_d<DPP_ROR8>(v));
+    if (G >= 32) v = fmin(v, __shfl_xor(v, 16));
+    if (G == 64) v = fmin(v, __shfl_xor(v, 32));
+    return v;
+}
+
 // 1/x for finite, normal x: v_rcp_f64 plus two Newton steps (full fp64 accuracy, a fifth of the instructions and of the
 // dependent latency of the IEEE division sequence; the operands here are pivots checked to be > 0, multipliers, rho, d)
 __device__ __forceinline__ double frcp(double x) {
@@ -234,10 +265,25 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
     {
 #pragma unroll
         for (int j = 0; j < RPL; ++j) x[j] = sKu[kuB + nx * NQ + ROWJ(j)];
-        for (int c = 0; c < nx; ++c) {
-            const double xc = sX0[li * nx + c];
+        // four columns of the map at a time, their LDS reads (16 bytes: a lane's rows come in pairs) issued before the first
+        // product: as a plain loop over a run-time nx every column waited for its own reads (11 % of the first pass of a
+        // component-split solve, in-kernel counters).  Same sums in the same order.
+        for (int c0 = 0; c0 < nx; c0 += 4) {
+            double xc[4]; double2 kv[4][RP];
 #pragma unroll
-            for (int j = 0; j < RPL; ++j) x[j] += sKu[kuB + c * NQ + ROWJ(j)] * xc;
+            for (int u = 0; u < 4; ++u) {
+                const bool in = c0 + u < nx;
+                const int c = in ? c0 + u : nx;             // row nx of the map (the constant term) is always there
+                xc[u] = in ? sX0[li * nx + c] : 0.0;
+#pragma unroll
+                for (int jj = 0; jj < RP; ++jj) kv[u][jj] = *reinterpret_cast<const double2*>(sKu + kuB + c * NQ + ROWJ(2 * jj));
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (c0 + u < nx) {
+#pragma unroll
+                    for (int jj = 0; jj < RP; ++jj) { x[2 * jj] += kv[u][jj].x * xc[u]; x[2 * jj + 1] += kv[u][jj].y * xc[u]; }
+                }
         }
         if constexpr (!SPLIT) {     // c0 = [x0;1]' Cq [x0;1], rows a = g, g+G, .. of the form in lane g (split: split_finish_kernel adds it)
             const int nx1 = nx + 1;
@@ -598,22 +644,27 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
     bool run = valid && !over && !fail;
     int guard = 0;
     for (;;) {
-        double best = 0.0; int code = -1;
+        static_assert(2 * NQ <= (1 << KEYBITS), "2 row + side must fit the key's index bits");
+        double bkey = 0.0;
         const unsigned m = mU | mL;
 #pragma unroll
-        for (int j = 0; j < RPL; ++j) {     // violation beyond the tolerance: x - (hi + tol) or (lo - tol) - x
+        for (int j = 0; j < RPL; ++j) {     // violation beyond the tolerance: x - (hi + tol) or (lo - tol) - x, as a key with (2 row + side)
             const int row = ROWJ(j);
             const double2 bt = sBT[bB + row];
-            const double vu = x[j] - bt.y, vl = bt.x - x[j];
-            const double v = fmax(vu, vl);
-            if (!((m >> j) & 1u) && v > best) { best = v; code = 2 * row + (vu > vl ? 1 : 0); }
+            const double kv = fmax(key_pack(x[j] - bt.y, 2 * row + 1), key_pack(bt.x - x[j], 2 * row));
+            // a row of the working set gets the sign bit: never the maximum (the chain starts at 0)
+            const int sgn = (int)((m >> j) << 31);
+            bkey = fmax(bkey, __hiloint2double(__double2hiint(kv) | sgn, __double2loint(kv)));
         }
-        grp_max<G>(best, code);
+        bkey = grp_fmax<G>(bkey);
+        const int code = bkey > 0.0 ? key_index(bkey) : -1;
+        double best = bkey;
         bool has = run && code >= 0;
         PROF_MARK(9);
-        if (code >= 0) {                    // the violation itself: add the row's tolerance back
-            const double hi = sUb[bB + (code >> 1)], lo = sLb[bB + (code >> 1)];
-            best += 1e-12 * bound_scale(lo, hi);
+        if (code >= 0) {                    // the violation itself: add the row's tolerance back (the violated side's, which is finite)
+            const int row = code >> 1;
+            const double2 bt = sBT[bB + row];
+            best += (code & 1) ? bt.y - sUb[bB + row] : sLb[bB + row] - bt.x;
         }
         if (!__any(has)) break;
         if (has && ++guard > p.max_steps) { fail = true; why = 5; run = false; has = false; }
@@ -637,16 +688,16 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
             if (inner && !(d2 > 0.0)) { fail = true; why = 4; run = false; inner = false; }
             const double rd2 = frcp(d2);
             const double t2 = viol * rd2;
-            double t1 = 1e300; int jb = BIGI;
+            static_assert(KMAX <= (1 << KEYBITS), "a slot index must fit the key's index bits");
+            double t1 = 1e300;              // the first blocking multiplier, as a key with its slot
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const double rr = sp * r[i];
-                if (sgO[i] * rr > 0.0) {
-                    const double t = lam[i] * frcp(rr);
-                    if (t < t1) { t1 = t; jb = G * i + g; }
-                }
+                const double t = key_pack(lam[i] * frcp(rr), G * i + g);
+                t1 = (sgO[i] * rr > 0.0) ? fmin(t1, t) : t1;
             }
-            grp_min<G>(t1, jb);
+            t1 = grp_fmin<G>(t1);
+            const int jb = t1 < 1e299 ? key_index(t1) : BIGI;
             const bool full = (t2 <= t1);
             // a full step needs a free slot for p: without one stop BEFORE the step, so that (x, lam, W) stay the consistent
             // state of the current working set -- that state is what the next pass is handed
@@ -1059,7 +1110,9 @@ __device__ __forceinline__ void oct_body_split(const PolParams& p) {
     }
     oct_block<G, RP, KMAX, THREADS, true, true>(p, slot, total, pacc, inst, xpre, sub, comp);
 #ifdef POLISH_PROF
-    if (lane == 0 && p.prof) {
+    // (every 16th workgroup reports: with all of them, 350 k atomics on 16 addresses back the memory pipeline up and the waves'
+    // own stores -- phase "out" -- appear to take three quarters of the launch)
+    if (lane == 0 && p.prof && (blockIdx.x & 15) == 0) {
         unsigned long long tot = 0;
         for (int i = 0; i < 16; ++i) { atomicAdd(p.prof + (G >= 16 ? 16 : 0) + i, pacc[i]); if (i != 7 && i != 8 && i != 14) tot += pacc[i]; }
         atomicMax(p.prof + (G >= 16 ? 16 : 0) + 15, tot);
