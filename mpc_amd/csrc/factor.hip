@@ -312,6 +312,16 @@ __device__ __forceinline__ double readlane_d(double v) {
     return __hiloint2double(hi, lo);
 }
 
+// acc += (lane C of the row of 16 lanes)'s src * w in ONE instruction: the 64-bit FMA takes its first operand through the DPP
+// row broadcast (gfx90a+), where v_readlane needs two reads into scalar registers and the product a third instruction.
+// The compiler does not see inside the statement, so the DPP hazard (a VALU write of the broadcast register within the two
+// instructions before) is kept off by hand: dpp_guard() after the value is computed, before its first broadcast.
+template <int C>
+__device__ __forceinline__ void fmac_bc(double& acc, double src, double w) {
+    asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(w), "n"(C));
+}
+__device__ __forceinline__ void dpp_guard(double& v) { asm volatile("s_nop 1" : "+v"(v)); }
+
 template <int J>
 struct DiagStep {
     // column J of the tile's Cholesky factor and the rank-1 update of the columns right of it
@@ -321,14 +331,16 @@ struct DiagStep {
         const double rs = piv > 0.0 ? frsqrt(piv) : 1.0;
         dinv[J] = rs;
         a[J] = r < J ? 0.0 : (r == J ? piv * rs : a[J] * rs);
-        update<J + 1>(a);
+        const double na = -a[J];
+        dpp_guard(a[J]);
+        update<J + 1>(a, na);
         DiagStep<J + 1>::run(a, dinv, r, bad);
     }
     template <int C>
-    static __device__ __forceinline__ void update(double (&a)[16]) {
+    static __device__ __forceinline__ void update(double (&a)[16], double na) {
         if constexpr (C < 16) {
-            a[C] -= a[J] * readlane_d<C>(a[J]);          // a_rC -= l_rJ l_CJ (meaningful for r >= C; zeroed at step C otherwise)
-            update<C + 1>(a);
+            fmac_bc<C>(a[C], a[J], na);                  // a_rC -= l_rJ l_CJ (meaningful for r >= C; zeroed at step C otherwise)
+            update<C + 1>(a, na);
         }
     }
 };
@@ -340,23 +352,25 @@ struct DiagStep<16> {
 template <int RR>
 struct InvStep {
     // entry RR of column r of T = L^-1: t_RR = (delta - sum_{k<RR} l_RR,k t_k) / l_RR,RR, row RR of L broadcast from lane RR
-    static __device__ __forceinline__ void run(const double (&a)[16], const double (&dinv)[16], double (&t)[16], int r) {
+    // (nt = -t is what the products take)
+    static __device__ __forceinline__ void run(const double (&a)[16], const double (&dinv)[16], double (&t)[16], double (&nt)[16], int r) {
         double acc = (RR == r) ? 1.0 : 0.0;
-        accum<0>(a, t, acc);
+        accum<0>(a, nt, acc);
         t[RR] = RR >= r ? acc * dinv[RR] : 0.0;
-        InvStep<RR + 1>::run(a, dinv, t, r);
+        nt[RR] = -t[RR];
+        InvStep<RR + 1>::run(a, dinv, t, nt, r);
     }
     template <int K>
-    static __device__ __forceinline__ void accum(const double (&a)[16], const double (&t)[16], double& acc) {
+    static __device__ __forceinline__ void accum(const double (&a)[16], const double (&nt)[16], double& acc) {
         if constexpr (K < RR) {
-            acc -= readlane_d<RR>(a[K]) * t[K];
-            accum<K + 1>(a, t, acc);
+            fmac_bc<RR>(acc, a[K], nt[K]);
+            accum<K + 1>(a, nt, acc);
         }
     }
 };
 template <>
 struct InvStep<16> {
-    static __device__ __forceinline__ void run(const double (&)[16], const double (&)[16], double (&)[16], int) {}
+    static __device__ __forceinline__ void run(const double (&)[16], const double (&)[16], double (&)[16], double (&)[16], int) {}
 };
 
 // ONE n x (16 NB + 1) matrix in LDS holds everything: Hs -> (lower off-diagonal tiles) L_ij, (diagonal tiles) T_bb =
@@ -483,11 +497,13 @@ __global__ __launch_bounds__(64, FACW) void factor_wave_kernel(FacBatchParams f)
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
         const int o = 16 * b;
-        double a[16], t[16], dinv[16];
+        double a[16], t[16], nt[16], dinv[16];
 #pragma unroll
         for (int j = 0; j < 16; ++j) a[j] = PADL(b == NB - 1, o + col, o + j);
         DiagStep<0>::run(a, dinv, col, bad);
-        InvStep<0>::run(a, dinv, t, col);
+#pragma unroll
+        for (int j = 0; j < 16; ++j) dpp_guard(a[j]);
+        InvStep<0>::run(a, dinv, t, nt, col);
         wv_sync();
         if (i < 16) {
 #pragma unroll
