@@ -28,6 +28,7 @@
 // larger pass; the last resort is the wave-per-instance kernel (polish.hip).
 //
 // Reference counterpart: as polish.hip -- the accuracy of soln['x'] (LaunchPlannerQPFormulation.py:174).
+#include <type_traits>
 #include "polish.h"
 #include <cstdlib>
 #include <algorithm>
@@ -127,6 +128,27 @@ __device__ __forceinline__ double key_pack(double v, int idx) {
     return __hiloint2double(__double2hiint(v), (__double2loint(v) & ~((1 << KEYBITS) - 1)) | idx);
 }
 __device__ __forceinline__ int key_index(double k) { return __double2loint(k) & ((1 << KEYBITS) - 1); }
+// acc += (lane C of my group of G lanes)'s src * w without a trip through LDS: the 64-bit FMA takes its first operand through
+// the DPP row broadcast (a "row" is 16 lanes; gfx90a+).  A group of 8 lanes is half a row: two instructions, each writing
+// the half of the row (bank_mask) whose lane it broadcasts.  Every lane of the wave must be active.  The compiler does not
+// see inside the statement: dpp_guard() keeps the DPP hazard (a VALU write of the broadcast register within the two
+// instructions before) off, and tools/check_dpp_hazard.py checks the listing.
+template <int G, int C>
+__device__ __forceinline__ void fmac_grp(double& acc, double src, double w) {
+    static_assert(G == 8 || G == 16, "groups of half a DPP row or a whole one");
+    if constexpr (G == 16) {
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(w), "n"(C));
+    } else {
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0x3" : "+v"(acc) : "v"(src), "v"(w), "n"(C));
+        asm("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xc" : "+v"(acc) : "v"(src), "v"(w), "n"(C + 8));
+    }
+}
+__device__ __forceinline__ void dpp_guard(double& v) { asm volatile("s_nop 1" : "+v"(v)); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (N > 0) { static_for<N - 1>(f); f(std::integral_constant<int, N - 1>{}); }
+}
+
 template <int G>
 __device__ __forceinline__ double grp_fmax(double v) {
     v = fmax(v, dpp_d<DPP_XOR1>(v));
@@ -181,6 +203,9 @@ constexpr int NBIN = 32;
 // end, and ~20 k atomics on ONE line were what the launch waited for after its last workgroup had finished computing
 constexpr int BIN_STRIDE = 32;
 
+#ifndef OCT_DPP
+#define OCT_DPP 1
+#endif
 #define OCT_LAYOUT \
     extern __shared__ __attribute__((aligned(16))) char smem[]; \
     constexpr int IPW = THREADS / G; \
@@ -189,6 +214,7 @@ constexpr int BIN_STRIDE = 32;
     constexpr int NQ = 2 * G * RP; \
     constexpr int LD = NQ; \
     constexpr int CH = (G >= 32) ? OCT_CH32 : 4, XCH = (G >= 32) ? OCT_XCH32 : 2; \
+    [[maybe_unused]] constexpr bool DPPH = OCT_DPP && (G == 16 || (G == 8 && KMAX == 8)), DPPR = OCT_DPP && G == 16; \
     const int n = p.n, nx = p.nx; \
     [[maybe_unused]] const int CN = SPLIT ? p.sp_C : 1; \
     const int tid = threadIdx.x, g = tid & (G - 1), li = tid / G; \
@@ -341,6 +367,22 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
     auto sinv_h = [&](int po, int lim, double (&r)[NS], double (&hown)[NS]) {
 #pragma unroll
         for (int i = 0; i < NS; ++i) r[i] = 0.0;
+        if constexpr (DPPH) {
+            // h at a slot is what the slot's owner reads for itself: broadcast from there (no list look-up, no gather)
+#pragma unroll
+            for (int i = 0; i < NS; ++i) { hown[i] = sHi[po + raO[i]]; dpp_guard(hown[i]); }
+            static_for<NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if (s == 0 || __any(G * s < lim)) {
+                    static_for<G>([&](auto gc) {
+                        constexpr int c = decltype(gc)::value;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) fmac_grp<G, c>(r[i], hown[s], W[i][G * s + c]);
+                    });
+                }
+            });
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < KMAX; cb += CH) {
             if (!__any(cb < lim)) break;
@@ -358,7 +400,22 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
         for (int i = 0; i < NS; ++i) hown[i] = sHi[po + raO[i]];
     };
     // W += coef_a * myR[c]
-    auto rank1 = [&](const double (&coef)[NS], int lim) {
+    auto rank1 = [&](const double (&coef)[NS], int lim, double (&uo)[NS]) {
+        if constexpr (DPPR) {           // uo: the vector myR holds, at its owners
+#pragma unroll
+            for (int i = 0; i < NS; ++i) dpp_guard(uo[i]);
+            static_for<NS>([&](auto sc) {
+                constexpr int s = decltype(sc)::value;
+                if (s == 0 || __any(G * s < lim)) {
+                    static_for<G>([&](auto gc) {
+                        constexpr int c = decltype(gc)::value;
+#pragma unroll
+                        for (int i = 0; i < NS; ++i) fmac_grp<G, c>(W[i][G * s + c], uo[s], coef[i]);
+                    });
+                }
+            });
+            return;
+        }
 #pragma unroll
         for (int cb = 0; cb < KMAX; cb += CH) {
             if (!__any(cb < lim)) break;
@@ -475,15 +532,16 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
             bool go = actt;
             if (go && !(d2 > 0.0)) { fail = true; why = 2; wact = false; go = false; }
             const double rd2 = go ? frcp(d2) : 0.0;
-            double coef[NS];
+            double coef[NS], uo[NS];
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const double u = (G * i + g == t) ? -1.0 : r[i];
-                myR[G * i + g] = u;
+                if constexpr (!DPPR) myR[G * i + g] = u;
+                uo[i] = u;
                 coef[i] = u * rd2;
             }
             wsync();
-            rank1(coef, min(t + 1, k0));
+            rank1(coef, min(t + 1, k0), uo);
             wsync();
         }
         if (fail) { live = 0ull; }
@@ -747,10 +805,13 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
                 if (app && (pos & (G - 1)) == g) { myR[pos] = -1.0; myA[pos] = pr; }
                 if (app) khi = max(khi, pos + 1);
                 wsync();
-                double coef[NS];
+                double coef[NS], uo[NS];
 #pragma unroll
-                for (int i = 0; i < NS; ++i) coef[i] = app ? ((G * i + g == pos) ? -rd2 : r[i] * rd2) : 0.0;
-                rank1(coef, khi);
+                for (int i = 0; i < NS; ++i) {
+                    uo[i] = (G * i + g == pos) ? -1.0 : r[i];
+                    coef[i] = app ? ((G * i + g == pos) ? -rd2 : r[i] * rd2) : 0.0;
+                }
+                rank1(coef, khi, uo);
                 if (app) {
 #pragma unroll
                     for (int i = 0; i < NS; ++i)
