@@ -43,8 +43,15 @@ namespace {
 constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E;     // quad_perm [1,0,3,2], [2,3,0,1]
 constexpr int DPP_HMIRROR = 0x141;                  // row_half_mirror: lane i <-> 7-i of each 8
 
+// The lane exchanges below are all inside a row of 16 lanes and run with every lane of the wave active, so the value a
+// disabled or out-of-row source would leave (bound_ctrl: zero) never shows; without an "old" operand the compiler emits
+// the two v_mov_b32_dpp alone (with update_dpp(v, v, ..) it copied the pair first: 5 instructions a step, not 2).
 template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xF, 0xF, false); }
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_mov_dpp(v, CTRL, 0xF, 0xF, true); }
+// v_max_f64 / v_min_f64 as they are: fmax() / fmin() first canonicalise every operand the compiler cannot prove quiet
+// (one more v_max_f64 each); the keys below are bit patterns put together by integer instructions, never NaN
+__device__ __forceinline__ double fmax_raw(double a, double b) { double r; asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ double fmin_raw(double a, double b) { double r; asm("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 template <int CTRL>
 __device__ __forceinline__ double dpp_d(double v) {
     return __hiloint2double(dpp_i<CTRL>(__double2hiint(v)), dpp_i<CTRL>(__double2loint(v)));
@@ -151,22 +158,22 @@ __device__ __forceinline__ void static_for(F&& f) {
 
 template <int G>
 __device__ __forceinline__ double grp_fmax(double v) {
-    v = fmax(v, dpp_d<DPP_XOR1>(v));
-    v = fmax(v, dpp_d<DPP_XOR2>(v));
-    if (G >= 8) v = fmax(v, dpp_d<DPP_HMIRROR>(v));
-    if (G >= 16) v = fmax(v, dpp_d<DPP_ROR8>(v));
-    if (G >= 32) v = fmax(v, __shfl_xor(v, 16));
-    if (G == 64) v = fmax(v, __shfl_xor(v, 32));
+    v = fmax_raw(v, dpp_d<DPP_XOR1>(v));
+    v = fmax_raw(v, dpp_d<DPP_XOR2>(v));
+    if (G >= 8) v = fmax_raw(v, dpp_d<DPP_HMIRROR>(v));
+    if (G >= 16) v = fmax_raw(v, dpp_d<DPP_ROR8>(v));
+    if (G >= 32) v = fmax_raw(v, __shfl_xor(v, 16));
+    if (G == 64) v = fmax_raw(v, __shfl_xor(v, 32));
     return v;
 }
 template <int G>
 __device__ __forceinline__ double grp_fmin(double v) {
-    v = fmin(v, dpp_d<DPP_XOR1>(v));
-    v = fmin(v, dpp_d<DPP_XOR2>(v));
-    if (G >= 8) v = fmin(v, dpp_d<DPP_HMIRROR>(v));
-    if (G >= 16) v = fmin(v, dpp_d<DPP_ROR8>(v));
-    if (G >= 32) v = fmin(v, __shfl_xor(v, 16));
-    if (G == 64) v = fmin(v, __shfl_xor(v, 32));
+    v = fmin_raw(v, dpp_d<DPP_XOR1>(v));
+    v = fmin_raw(v, dpp_d<DPP_XOR2>(v));
+    if (G >= 8) v = fmin_raw(v, dpp_d<DPP_HMIRROR>(v));
+    if (G >= 16) v = fmin_raw(v, dpp_d<DPP_ROR8>(v));
+    if (G >= 32) v = fmin_raw(v, __shfl_xor(v, 16));
+    if (G == 64) v = fmin_raw(v, __shfl_xor(v, 32));
     return v;
 }
 
@@ -709,21 +716,20 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
         for (int j = 0; j < RPL; ++j) {     // violation beyond the tolerance: x - (hi + tol) or (lo - tol) - x, as a key with (2 row + side)
             const int row = ROWJ(j);
             const double2 bt = sBT[bB + row];
-            const double kv = fmax(key_pack(x[j] - bt.y, 2 * row + 1), key_pack(bt.x - x[j], 2 * row));
-            // a row of the working set gets the sign bit: never the maximum (the chain starts at 0)
+            const double kv = fmax_raw(key_pack(x[j] - bt.y, 2 * row + 1), key_pack(bt.x - x[j], 2 * row));
+            // a row of the working set gets the sign bit: never the maximum unless nothing is violated (and then it is not positive)
             const int sgn = (int)((m >> j) << 31);
-            bkey = fmax(bkey, __hiloint2double(__double2hiint(kv) | sgn, __double2loint(kv)));
+            const double km = __hiloint2double(__double2hiint(kv) | sgn, __double2loint(kv));
+            bkey = j == 0 ? km : fmax_raw(bkey, km);
         }
         bkey = grp_fmax<G>(bkey);
         const int code = bkey > 0.0 ? key_index(bkey) : -1;
-        double best = bkey;
         bool has = run && code >= 0;
         PROF_MARK(9);
-        if (code >= 0) {                    // the violation itself: add the row's tolerance back (the violated side's, which is finite)
-            const int row = code >> 1;
-            const double2 bt = sBT[bB + row];
-            best += (code & 1) ? bt.y - sUb[bB + row] : sLb[bB + row] - bt.x;
-        }
+        // the violation itself: add the row's tolerance back (the violated side's, which is finite): |staged bound - bound|,
+        // read without a branch on the side (no violation: row 0's, unused)
+        const int vrow = max(code, 0) >> 1, vside = code & 1;
+        const double best = bkey + fabs(reinterpret_cast<const double*>(sBT)[2 * (bB + vrow) + vside] - sLb[vside * (CN * NQ) + bB + vrow]);
         if (!__any(has)) break;
         if (has && ++guard > p.max_steps) { fail = true; why = 5; run = false; has = false; }
         const int pr = has ? (code >> 1) : 0;
@@ -752,7 +758,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
             for (int i = 0; i < NS; ++i) {
                 const double rr = sp * r[i];
                 const double t = key_pack(lam[i] * frcp(rr), G * i + g);
-                t1 = (sgO[i] * rr > 0.0) ? fmin(t1, t) : t1;
+                t1 = (sgO[i] * rr > 0.0) ? fmin_raw(t1, t) : t1;
             }
             t1 = grp_fmin<G>(t1);
             const int jb = t1 < 1e299 ? key_index(t1) : BIGI;
@@ -1069,7 +1075,7 @@ __device__ __forceinline__ void oct_body(const PolParams& p) {
         sUb[j] = hi;
         sD[j] = (j < n) ? p.d[j] : 0.0;
         const double tol = 1e-12 * bound_scale(lo, hi);
-        sBT[j] = make_double2(lo - tol, hi + tol);
+        sBT[j] = make_double2(fmax(lo - tol, -1e300), fmin(hi + tol, 1e300));   // finite: the keyed scan packs bits into x - bound
     }
     {   // the map [Ku | ku]': (nx+1) rows of NQ, 16-byte loads
         // (NP and NQ are multiples of 16), four in flight per thread
@@ -1165,7 +1171,7 @@ __device__ __forceinline__ void oct_body_split(const PolParams& p) {
             const double lo = j < sl ? p.lbs[c * sl + j] : -1e300, hi = j < sl ? p.ubs[c * sl + j] : 1e300;
             sLb[idx] = lo; sUb[idx] = hi; sD[idx] = j < sl ? p.d[c * sl + j] : 0.0;
             const double tol = 1e-12 * bound_scale(lo, hi);
-            sBT[idx] = make_double2(lo - tol, hi + tol);
+            sBT[idx] = make_double2(fmax(lo - tol, -1e300), fmin(hi + tol, 1e300));     // finite: the keyed scan packs bits into x - bound
             sPerm[idx] = j < sl ? p.sp_perm[c * sl + j] : -1;
         }
     }
