@@ -757,7 +757,7 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
 #pragma unroll
             for (int i = 0; i < NS; ++i) {
                 const double rr = sp * r[i];
-                const double t = key_pack(lam[i] * frcp(rr), G * i + g);
+                const double t = key_pack(fmin(lam[i] * frcp(rr), 1e300), G * i + g);     // finite: an infinity with index bits would be a NaN
                 t1 = (sgO[i] * rr > 0.0) ? fmin_raw(t1, t) : t1;
             }
             t1 = grp_fmin<G>(t1);
@@ -1453,8 +1453,8 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) cr[r] += __shfl_xor(cr[r], off);
+            // over the 16 lanes of a DPP row by rotations (as the counts below): no trips through the LDS crossbar
+            cr[r] += dpp_d<0x128>(cr[r]); cr[r] += dpp_d<0x124>(cr[r]); cr[r] += dpp_d<0x122>(cr[r]); cr[r] += dpp_d<0x121>(cr[r]);
             const int inst = blockIdx.x * 64 + wave * 16 + kq + 4 * r;
             if (col == 0 && inst < p.B) c0out[inst] = 0.5 * cr[r];
         }
