@@ -863,6 +863,16 @@ __device__ __forceinline__ void oct_block(const PolParams& p, const int slot, co
 
     PROF_MARK(5);
     // ---- outputs --------------------------------------------------------------------------------------
+    // The keyed scan trusts its operands to be finite: a NaN key is dropped by v_max_f64 and would read as "nothing violated".
+    // The staged bounds are finite by construction; an x that is not (overflow, NaN data) fails the instance here, once per
+    // solve, and the next pass / the any-size kernel (which has no keys) takes it.
+    {
+        bool xbad = false;
+#pragma unroll
+        for (int j = 0; j < RPL; ++j) xbad = xbad || !(fabs(x[j]) < 1e300);
+        const unsigned long long nb = __ballot(xbad);
+        if (G == 64 ? nb != 0ull : ((nb >> (lane & ~(G - 1))) & ((1ull << (G & 63)) - 1ull)) != 0ull) { fail = true; if (!why) why = 10; }
+    }
     const bool okk = valid && !over && !fail;
     int qslot = -1;
     if (valid && g == 0) {

@@ -72,7 +72,7 @@ __global__ void split_pack_kernel(const double* Hi, const double* KuT, const dou
         const double lo = gj >= 0 ? lbs[gj] : -1e300, hi = gj >= 0 ? ubs[gj] : 1e300;
         iLb[idx] = lo; iUb[idx] = hi; iD[idx] = gj >= 0 ? d[gj] : 0.0;
         const double tol = 1e-12 * bound_scale(lo, hi);
-        iBT[2 * idx] = lo - tol; iBT[2 * idx + 1] = hi + tol;
+        iBT[2 * idx] = fmax(lo - tol, -1e300); iBT[2 * idx + 1] = fmin(hi + tol, 1e300);    // finite: the keyed scan packs bits into x - bound (polish_quad.hip)
         iPerm[idx] = gj;
     }
     for (int idx = gid; idx < C * nx1 * ld; idx += gsz) {

@@ -165,3 +165,21 @@ def test_refactoring_with_other_weights_finds_the_split_again():
     U = pl.solve(x0).cpu().numpy().reshape(256, -1)
     assert pl.split_info()["components"] == 4
     _check_against_oracle(pl, prob2, U, every=64)
+
+
+@pytest.mark.parametrize("batch", [300, 20000])
+def test_one_sided_bounds_on_the_split_path(batch):
+    """A channel without a lower bound and one without an upper bound, solved block by block.  The scan of the active-set
+    passes packs a row index into the low bits of x - bound: an infinite bound there would make a NaN pattern of it (the
+    staged bounds are kept finite for that reason; polish_quad.hip)."""
+    prob = _block_problem([(3, 1), (3, 1), (4, 1)], N=16, batch=batch, seed=21, ubound=0.25, x0_amp=4.0, stab=0.9)
+    prob["u_min"] = np.array([-np.inf, -0.25, -0.2]); prob["u_max"] = np.array([0.2, np.inf, 0.25])
+    pl = _planner(prob)
+    U = pl.solve(prob["x0"]).cpu().numpy().reshape(batch, -1)
+    assert pl.split_info()["components"] == 3
+    assert (pl.info.status.cpu().numpy() == 0).all()
+    free = _check_against_oracle(pl, prob, U, every=max(1, batch // 10))
+    assert (~free).sum() > batch          # the finite sides do bind
+    pu = _planner(prob, split=False)
+    Uu = pu.solve(prob["x0"]).cpu().numpy().reshape(batch, -1)
+    assert np.abs(U - Uu).max() <= 1e-9 * max(1.0, np.abs(Uu).max())
