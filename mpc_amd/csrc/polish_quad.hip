@@ -1394,7 +1394,9 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
     double* sUb = sLb + NQ;
     double* sDd = sUb + NQ;
     double* sX = sDd + NQ;                              // (64, XS): [x0; 1; 0..] of this block's instances
-    int* sComp = reinterpret_cast<int*>(sX + 64 * XS);  // (NQ): component of the row
+    const int CA = 16 * ((nx + 1 + 15) / 16), CQS = KP + 1;
+    double* sCq = sX + 64 * XS;                         // (CA, CQS): Cq, zero padded (odd stride: 16 rows on 16 banks)
+    int* sComp = reinterpret_cast<int*>(sCq + (size_t)CA * CQS);  // (NQ): component of the row
     {
         const int hq = NQ / 2, tot2 = KP * hq;
         constexpr int U = 4;
@@ -1432,6 +1434,12 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
             for (int u = 0; u < U; ++u) if (b0 + u * 256 < 64 * KP) sX[off[u]] = v[u];
         }
     }
+    // the quadratic form's matrix rides along with the staging: read from global memory inside the product loop, its latency
+    // was on the critical path of every workgroup (in-kernel stamps: 6 of a workgroup's 16 us between staging and counts)
+    for (int idx = tid; idx < CA * CQS; idx += 256) {
+        const int a = idx / CQS, k = idx - a * CQS;
+        sCq[idx] = (a <= nx && k <= nx) ? p.Cq[(size_t)a * (nx + 1) + k] : 0.0;
+    }
     if (tid < NBIN) hist[tid] = 0;
     if (blockIdx.x == 0 && tid == 0) *redo_count = 0;       // the one counter the last solve's finish kernel could not clear
     __syncthreads();
@@ -1455,8 +1463,7 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
             d4 cacc = d4{0, 0, 0, 0};
             for (int s = 0; s < KS; ++s) {
                 const int k = 4 * s + kq;
-                const double bq = (a < nx1 && k < nx1) ? p.Cq[(size_t)a * nx1 + k] : 0.0;
-                cacc = mfma_f64(xrow[k], bq, cacc);
+                cacc = mfma_f64(xrow[k], sCq[a * CQS + k], cacc);
             }
 #pragma unroll
             for (int r = 0; r < 4; ++r) cr[r] += cacc[r] * (a < nx1 ? sX[(size_t)(wave * 16 + kq + 4 * r) * XS + a] : 0.0);
@@ -1492,24 +1499,6 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
         cnt[r] = ((unsigned long long)(unsigned)hi << 32) | (unsigned)lo;
     }
     const int inst0 = blockIdx.x * 64 + wave * 16;
-    // rows of the components that x_unc solves
-#pragma unroll
-    for (int t = 0; t < 8; ++t)
-        if (t < NT) {
-            const int row = 16 * t + col;
-            const int sh = 8 * sComp[row];
-            const double dd = sDd[row];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int inst = inst0 + kq + 4 * r;
-                if (row < n && inst < p.B && ((cnt[r] >> sh) & 0xFFull) == 0ull) {
-                    const double xv = acc[t][r];
-                    p.U[(size_t)inst * n + row] = dd * xv;
-                    if (p.keep_state) { p.z[(size_t)inst * p.NP + row] = xv; p.w[(size_t)inst * p.NP + row] = 0.0; }
-                    if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0;
-                }
-            }
-        }
     // one lane per (instance, component): done, or into its bucket
     int mk[2] = {0, 0}, ml[2] = {0, 0}, ms[2] = {0, 0};
 #pragma unroll
@@ -1528,7 +1517,30 @@ __global__ __launch_bounds__(256) void split_key_kernel(PolParams p, const int* 
         }
     }
     __syncthreads();
-    if (tid < NBIN && hist[tid]) base[tid] = atomicAdd(&bins[tid * BIN_STRIDE], hist[tid]);
+    // the workgroup's places in the buckets: asked for here, needed after the stores below (the atomic's round trip to the
+    // memory side, ~2 us, hides behind them)
+    const bool asks = tid < NBIN && hist[tid] != 0;
+    int got = 0;
+    if (asks) got = atomicAdd(&bins[tid * BIN_STRIDE], hist[tid]);
+    // rows of the components that x_unc solves
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+        if (t < NT) {
+            const int row = 16 * t + col;
+            const int sh = 8 * sComp[row];
+            const double dd = sDd[row];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int inst = inst0 + kq + 4 * r;
+                if (row < n && inst < p.B && ((cnt[r] >> sh) & 0xFFull) == 0ull) {
+                    const double xv = acc[t][r];
+                    p.U[(size_t)inst * n + row] = dd * xv;
+                    if (p.keep_state) { p.z[(size_t)inst * p.NP + row] = xv; p.w[(size_t)inst * p.NP + row] = 0.0; }
+                    if (p.info.lam) p.info.lam[(size_t)inst * n + row] = 0.0;
+                }
+            }
+        }
+    if (asks) base[tid] = got;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 2; ++u)
@@ -1539,7 +1551,8 @@ int launch_split_key(const PolParams& p, const int* rowmap, int* need, int* bins
                      hipStream_t st) {
     if (p.sp_C > 8 || p.n > 128) return -1;
     const int kp = 4 * ((p.nx + 4) / 4), nq = 16 * ((p.n + 15) / 16);
-    const size_t kl = ((size_t)kp * nq + 3 * nq + 64 * (size_t)(kp + 1)) * sizeof(double) + nq * sizeof(int);
+    const int ca = 16 * ((p.nx + 1 + 15) / 16);
+    const size_t kl = ((size_t)kp * nq + 3 * nq + 64 * (size_t)(kp + 1) + (size_t)ca * (kp + 1)) * sizeof(double) + nq * sizeof(int);
     if (kl > 64 * 1024) return -1;
     hipLaunchKernelGGL(split_key_kernel, dim3(ceil_div(p.B, 64)), dim3(256), kl, st, p, rowmap, need, bins, seg, c0out, redo_count);
     return (int)hipGetLastError();
