@@ -73,26 +73,6 @@ __device__ __forceinline__ double grp_sum(double v) {
     return v;
 }
 template <int CTRL>
-__device__ __forceinline__ void min_step(double& t, int& j) {
-    const double ot = dpp_d<CTRL>(t); const int oj = dpp_i<CTRL>(j);
-    if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
-}
-// (smallest t, its index; ties to the lower index) over the group
-template <int G>
-__device__ __forceinline__ void grp_min(double& t, int& j) {
-    min_step<DPP_XOR1>(t, j); min_step<DPP_XOR2>(t, j);
-    if (G >= 8) min_step<DPP_HMIRROR>(t, j);
-    if (G >= 16) min_step<DPP_ROR8>(t, j);
-    if (G >= 32) {
-        const double ot = __shfl_xor(t, 16); const int oj = __shfl_xor(j, 16);
-        if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
-    }
-    if (G == 64) {
-        const double ot = __shfl_xor(t, 32); const int oj = __shfl_xor(j, 32);
-        if (ot < t || (ot == t && oj < j)) { t = ot; j = oj; }
-    }
-}
-template <int CTRL>
 __device__ __forceinline__ void imin_step(int& j) { const int oj = dpp_i<CTRL>(j); j = oj < j ? oj : j; }
 template <int G>
 __device__ __forceinline__ int grp_imin(int j) {
@@ -103,26 +83,6 @@ __device__ __forceinline__ int grp_imin(int j) {
     if (G == 64) { const int oj = __shfl_xor(j, 32); j = oj < j ? oj : j; }
     return j;
 }
-template <int CTRL>
-__device__ __forceinline__ void max_step(double& v, int& code) {
-    const double ov = dpp_d<CTRL>(v); const int oc = dpp_i<CTRL>(code);
-    if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
-}
-template <int G>
-__device__ __forceinline__ void grp_max(double& v, int& code) {
-    max_step<DPP_XOR1>(v, code); max_step<DPP_XOR2>(v, code);
-    if (G >= 8) max_step<DPP_HMIRROR>(v, code);
-    if (G >= 16) max_step<DPP_ROR8>(v, code);
-    if (G >= 32) {
-        const double ov = __shfl_xor(v, 16); const int oc = __shfl_xor(code, 16);
-        if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
-    }
-    if (G == 64) {
-        const double ov = __shfl_xor(v, 32); const int oc = __shfl_xor(code, 32);
-        if (ov > v || (ov == v && oc >= 0 && (code < 0 || oc < code))) { v = ov; code = oc; }
-    }
-}
-
 constexpr int BIGI = 1 << 20;
 
 // Reductions that carry an index in the value.  A positive double orders like its bit pattern, so with the low KEYBITS bits

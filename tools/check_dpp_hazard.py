@@ -1,6 +1,7 @@
 """Static check of the hand-written DPP instructions in a gfx950 assembly listing (hipcc --save-temps): the compiler's
 hazard recogniser does not look inside inline asm, so this walks back from every *_dpp line and fails if a VALU
-instruction writes the DPP source register less than two wait states before it (s_nop k counts k + 1)."""
+instruction writes the DPP source register less than two wait states before it, or writes EXEC (v_cmpx*, a VALU
+destination of exec) less than five before it (s_nop k counts k + 1)."""
 import re
 import sys
 
@@ -26,16 +27,19 @@ def main(path):
         src = regs(ops[1].split()[0])
         waits = 0
         j = k - 1
-        while j >= 0 and waits < 2:
+        while j >= 0 and waits < 5:
             p = ins[j]
             name = p.split()[0]
             if name == "s_nop":
                 waits += int(p.split()[1], 0) + 1
             else:
                 if name.startswith("v_"):
-                    d = regs(p.split(None, 1)[1].split(",")[0].strip())
-                    if d & src:
-                        print("HAZARD:", p, "->", l)
+                    dst = p.split(None, 1)[1].split(",")[0].strip() if len(p.split(None, 1)) > 1 else ""
+                    if waits < 2 and regs(dst) & src:
+                        print("HAZARD (source written):", p, "->", l)
+                        bad += 1
+                    if name.startswith("v_cmpx") or dst.startswith("exec"):
+                        print("HAZARD (EXEC written):", p, "->", l)
                         bad += 1
                 waits += 1
             j -= 1
