@@ -23,6 +23,9 @@
 //     principal submatrix of Hi, cond <= cond(Hs), and there are at most a few dozen updates).
 //     Vectors a whole group needs (r, W[j,:], the row list) are exchanged through a per-instance LDS
 //     scratch; scalars are reduced with DPP (quad_perm, row_half_mirror, row_ror) and one ds_bpermute for G = 32.
+//     "Which row / which slot" reductions carry the index in the low mantissa bits of the value (key_pack): one v_max_f64 or
+//     v_min_f64 per butterfly step.  Where a vector held one element per lane meets per-lane rows (r = W h; the rank-one
+//     update for G = 16) the 64-bit FMA takes the element through the DPP row broadcast (fmac_grp) instead of LDS.
 //   * the instances of a wave advance in lock-step (one add/drop per round, predicated).
 // Instances whose active set outgrows KMAX (or that hit a numerical guard) are queued on the device for the next,
 // larger pass; the last resort is the wave-per-instance kernel (polish.hip).
