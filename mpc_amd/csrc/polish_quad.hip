@@ -1216,7 +1216,8 @@ int launch_oct_split(const PolParams& p, int slots, hipStream_t st) {
     // Measured and dropped (65,536 instances of configs[2], first pass 136 us): 4 lanes per sub-instance (16 per wave: 181 VGPRs,
     // or 120 spilled at the 128 this occupancy needs: 144 / 187 us); 256-thread workgroups (154 us: twice the staging);
     // wave-persistent workgroups with the next unit's data prefetched (146 - 184 us: the loop around the solve costs more
-    // registers than its prologue saves)
+    // registers than its prologue saves); 640-thread workgroups at five waves per SIMD after the instruction-level pass had
+    // brought the body to 103 VGPRs (96 + 72 bytes of scratch: 232 us per solve against 179)
     if (slots == 8) {
         if (n <= 16) return launch_oct_c<8, 1, 8, 512, true, true, 4>(p, p.B, st);
         if (n <= 32) return launch_oct_c<8, 2, 8, 512, true, true, 4>(p, p.B, st);
